@@ -1,0 +1,663 @@
+"""CPU oracle for the surfh forward/adjoint + CG hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a float64 NumPy/SciPy restatement of the reference algorithm
+(sidiso/surfh @ 2025-02-04).  It exists to CHECK the HIP product path and to
+serve as the timed CPU baseline in ``bench.py``; it is never the thing that is
+shipped.  Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg may import it.  Nothing under ``surfh_amd/`` imports it.
+
+Pinning: every stage below is compared, in this container, against the real
+reference modules imported from ``/root/reference`` (``oracle/ref_harness.py``)
+and against the golden vectors those modules produced
+(``tests/golden/*.npz``, generator ``tests/golden/make_golden.py``).
+Two third-party pieces are absent from the reference tree and are restated
+from their published behaviour: ``udft.ir2fr`` (udft 3.4.0) and ``qmm.lcg``
+(qmm 0.18.2).  ``lcg`` has no reference-side golden: *parity unpinned* for the
+solver (checked against a dense solve instead).
+
+Style: procedural, table driven.  It deliberately does not share code with
+``surfh_amd`` (the product's host side mirrors the reference's class API
+instead), so the two are independent implementations of the same geometry.
+
+All ``file:line`` citations are relative to ``/root/reference``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from math import ceil, floor
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import scipy.fft as sfft
+
+
+# ----------------------------------------------------------------------------
+# Fourier helpers
+# ----------------------------------------------------------------------------
+def dft(x):
+    """Unitary rfft2 on the last two axes (surfh/ToolsDir/python_utils.py:59-71)."""
+    return sfft.rfftn(x, axes=(-2, -1), norm="ortho", workers=-1)
+
+
+def idft(xf, shape):
+    """Unitary irfft2 (surfh/ToolsDir/python_utils.py:41-57)."""
+    return sfft.irfftn(xf, s=tuple(shape), axes=(-2, -1), norm="ortho", workers=-1)
+
+
+def ir2fr(imp_resp, shape, real=True):
+    """Restatement of ``udft.ir2fr`` (udft 3.4.0, absent from the reference tree).
+
+    Zero-pad the impulse response to ``shape`` on the last ``len(shape)`` axes,
+    roll its centre ``floor(n/2)`` to index 0, un-normalised (r)fftn.
+    Call sites: surfh/Models/spectroModelChannel.py:81-83,
+    scripts/main_fusion.py:98, test/test_fw_ad.py:507.
+    """
+    imp_resp = np.asarray(imp_resp)
+    nd = len(shape)
+    lead = imp_resp.shape[:-nd]
+    padded = np.zeros(lead + tuple(shape), dtype=imp_resp.dtype)
+    padded[(Ellipsis,) + tuple(slice(0, s) for s in imp_resp.shape[-nd:])] = imp_resp
+    for k, n in enumerate(imp_resp.shape[-nd:]):
+        padded = np.roll(padded, -int(np.floor(n / 2)), axis=imp_resp.ndim - nd + k)
+    if real:
+        return np.fft.rfftn(padded, axes=tuple(range(-nd, 0)))
+    return np.fft.fftn(padded, axes=tuple(range(-nd, 0)))
+
+
+# ----------------------------------------------------------------------------
+# LMM (surfh/ToolsDir/python_utils.py:11-35)
+# ----------------------------------------------------------------------------
+def lmm_maps2cube(maps, tpls):
+    return np.tensordot(tpls.T, maps, axes=(1, 0))
+
+
+def lmm_cube2maps(cube, tpls):
+    return np.tensordot(tpls, cube, axes=(1, 0))
+
+
+# ----------------------------------------------------------------------------
+# Geometry (surfh/Models/instru.py)
+# ----------------------------------------------------------------------------
+def rotmatrix(degree):
+    """instru.py:36-45"""
+    t = np.radians(degree)
+    return np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+
+
+def pix(value, step):
+    """Coord.pix: python (banker's) round to the grid (instru.py:143-145)."""
+    return round(value / step) * step
+
+
+def get_srf(det_pix_size, step_arcsec):
+    """instru.py:67-84"""
+    return int(det_pix_size // step_arcsec)
+
+
+def fov_local_axis(width, margin, step):
+    """One axis of FOV.local_coords (instru.py:283-304)."""
+    start = -width / 2 - margin
+    length = width + 2 * margin
+    round_start = int(floor(start / step)) * step
+    num = int(ceil((length + (start - round_start)) / step))
+    return np.arange(num + 1) * step + round_start
+
+
+def wslice_of(wavel_in, wmin, wmax, margin):
+    """IFU.wslice (instru.py:649-658); stop excludes the last in-range plane."""
+    lo = np.flatnonzero(wavel_in <= max(wmin - margin, wavel_in.min()))[-1]
+    hi = np.flatnonzero(wavel_in >= min(wmax + margin, wavel_in.max()))[0]
+    return int(lo), int(hi)
+
+
+def local2global(la, lb, angle, origin):
+    """FOV.local2global (instru.py:306-321)."""
+    na, nb = len(la), len(lb)
+    A = np.tile(la.reshape((-1, 1)), [1, nb])
+    B = np.tile(lb.reshape((1, -1)), [na, 1])
+    c = rotmatrix(angle) @ np.vstack((A.ravel(), B.ravel()))
+    return c[0].reshape((na, nb)) + origin[0], c[1].reshape((na, nb)) + origin[1]
+
+
+def global2local(ga, gb, angle, origin):
+    """FOV.global2local (instru.py:323-340)."""
+    na, nb = len(ga), len(gb)
+    ga = ga - origin[0]
+    gb = gb - origin[1]
+    A = np.tile(ga.reshape((-1, 1)), [1, nb])
+    B = np.tile(gb.reshape((1, -1)), [na, 1])
+    c = rotmatrix(-angle) @ np.vstack((A.ravel(), B.ravel()))
+    return c[0].reshape((na, nb)), c[1].reshape((na, nb))
+
+
+def spectral_psf(grating_resolution, out_axis, beta, wavelength, scale, n_margin=15):
+    """SpectralBlur.psfs, type='mrs' (instru.py:499-572).
+
+    Returns W[lambda', lambda, beta]; normalised over the margin-extended input
+    axis and then cropped (row sums are < 1 near the ends of the axis).
+    Note ``np.sinc(np.pi * z)`` = sin(pi^2 z)/(pi^2 z): kept as in the reference.
+    """
+    grating_len = 2 * 0.44245 / np.pi * grating_resolution
+    delta_w = min(np.diff(wavelength))
+    beta = np.asarray(beta).reshape((1, 1, -1))
+    out_axis = np.asarray(out_axis).reshape((-1, 1, 1))
+    wavelength = np.asarray(wavelength)
+    w_norm = np.concatenate(
+        [
+            np.linspace(wavelength.min() - n_margin * delta_w, wavelength.min() - delta_w, n_margin - 1),
+            wavelength,
+            np.linspace(wavelength.max() + delta_w, wavelength.max() + n_margin * delta_w, n_margin - 1),
+        ]
+    ).reshape((1, -1, 1))
+    out = (np.pi * grating_len / w_norm
+           * np.sinc(np.pi * grating_len * ((out_axis - scale * beta) / w_norm - 1)) ** 2)
+    out /= np.sum(out, axis=1, keepdims=True)
+    return out[:, n_margin - 1: -n_margin + 1, :]
+
+
+# ----------------------------------------------------------------------------
+# Bilinear tables (surfh/ToolsDir/cythons_files.pyx:20-154)
+# ----------------------------------------------------------------------------
+def find_indices(axis, values):
+    """Interval index and normalised distance for each value.
+
+    ``x[i] <= v < x[i+1]`` by search on the ACTUAL axis values, interval closed
+    on the right end, out-of-range clamped to the first/last interval
+    (find_interval_ascending with extrapolate=1, cythons_files.pyx:20-103).
+    """
+    axis = np.asarray(axis, dtype=np.float64)
+    v = np.asarray(values, dtype=np.float64)
+    n = len(axis)
+    idx = np.clip(np.searchsorted(axis, v, side="right") - 1, 0, n - 2)
+    frac = (v - axis[idx]) / (axis[idx + 1] - axis[idx])
+    return idx.astype(np.int64), frac
+
+
+def bilinear_apply(cube, i0, i1, y0, y1):
+    """solve_2D_hypercube (cythons_files.pyx:163-193): same weights, same order."""
+    w1 = (1.0 - y0) * (1.0 - y1)
+    w2 = (1.0 - y0) * y1
+    w3 = y0 * (1.0 - y1)
+    w4 = y0 * y1
+    out = cube[:, i0, i1] * w1
+    out = out + cube[:, i0, i1 + 1] * w2
+    out = out + cube[:, i0 + 1, i1] * w3
+    out = out + cube[:, i0 + 1, i1 + 1] * w4
+    return out
+
+
+# ----------------------------------------------------------------------------
+# Channel description and tables
+# ----------------------------------------------------------------------------
+@dataclass
+class ChannelSpec:
+    """What the reference passes as ``instru.IFU`` (instru.py:575-697)."""
+    alpha_width: float          # degrees
+    beta_width: float           # degrees
+    origin: Tuple[float, float]  # degrees
+    angle: float                # degrees
+    det_pix_size: float         # arcsec
+    n_slit: int
+    grating_resolution: float
+    wavel_axis: np.ndarray      # detector lambda' axis
+    name: str = "_"
+
+
+@dataclass
+class ChannelTables:
+    spec: ChannelSpec
+    srf: int
+    origin_pix: Tuple[float, float]
+    pointings: List[Tuple[float, float]]
+    wslice: Tuple[int, int]
+    local_alpha_axis: np.ndarray
+    local_beta_axis: np.ndarray
+    npix_slit_alpha_width: int
+    npix_slit_beta_width: int
+    n_alpha_out: int
+    slit_slices: List[Tuple[int, int, int, int]]     # (a0, a1, b0, b1) per slit
+    slit_weights: List[np.ndarray]                   # [na_s, nb_s] per slit
+    wpsf: np.ndarray                                 # [Ldet, Lin, nbeta]
+    oshape: Tuple[int, int, int, int]
+    grid_idx: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)   # per pointing (i0, i1) [na*nb]
+    grid_frac: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)  # per pointing (y0, y1)
+
+
+def _slit_local_fov(spec: ChannelSpec, s: int):
+    """Slicer.slit_local_fov (slicer.py:87-90) -> (alpha_start, alpha_end, beta_start, beta_end).
+
+    LocalFOV is centred at (0,0)+slit_shift; beta bounds are rounded to 9 decimals
+    (instru.py:420-434), alpha bounds are not.
+    """
+    sbw = spec.beta_width / spec.n_slit
+    shift_beta = (-spec.beta_width / 2 + sbw / 2) + s * sbw   # IFU.__post_init__ instru.py:612-617
+    ob = 0 + shift_beta
+    a_start = 0 - spec.alpha_width / 2
+    a_end = 0 + spec.alpha_width / 2
+    b_start = round(ob - sbw / 2, 9)
+    b_end = round(ob + sbw / 2, 9)
+    return a_start, a_end, b_start, b_end
+
+
+def _to_slices(fovb, la, lb):
+    """LocalFOV.to_slices (instru.py:436-459)."""
+    a_start, a_end, b_start, b_end = fovb
+    astep = la[1] - la[0]
+    bstep = lb[1] - lb[0]
+    a0 = np.flatnonzero(a_start < la + astep / 2)[0]
+    a1 = np.flatnonzero(la - astep / 2 < a_end)[-1] + 1
+    b0 = np.flatnonzero(b_start < lb + bstep / 2)[0]
+    b1 = np.flatnonzero(lb - bstep / 2 < b_end)[-1] + 1
+    return int(a0), int(a1), int(b0), int(b1)
+
+
+def _slit_slices(spec, s, la, lb, npix_a, npix_b, n_alpha_out):
+    """Slicer.get_slit_slices incl. both trimming hacks (slicer.py:118-145)."""
+    fovb = _slit_local_fov(spec, s)
+    a0, a1, b0, b1 = _to_slices(fovb, la, lb)
+    if (b1 - b0) > npix_b:
+        if abs(lb[b1] - fovb[3]) > abs(lb[b0] - fovb[2]):
+            b1 -= 1
+        else:
+            b0 += 1
+    if n_alpha_out % 2 == 0 and n_alpha_out < 28:
+        if (a1 - a0) > npix_a:
+            a1 -= 1
+        elif (a1 - a0) < npix_a:
+            a0 -= 2
+    return a0, a1, b0, b1
+
+
+def _fov_weight(fovb, sl, la, lb):
+    """Slicer.fov_weight (slicer.py:187-244): only the beta edges are weighted."""
+    a0, a1, b0, b1 = sl
+    bstep = lb[1] - lb[0]
+    sel_b = lb[b0:b1]
+    w = np.ones((a1 - a0, b1 - b0))
+    if sel_b[0] - bstep / 2 < fovb[2]:
+        wg = 1 - abs(sel_b[0] - bstep / 2 - fovb[2]) / bstep
+        assert 0 <= wg <= 1
+        w[:, 0] = wg
+    if sel_b[-1] + bstep / 2 > fovb[3]:
+        wg = 1 - abs(sel_b[-1] + bstep / 2 - fovb[3]) / bstep
+        assert 0 <= wg <= 1
+        w[:, -1] = wg
+    return w
+
+
+def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_degree,
+                  pointings: Sequence[Tuple[float, float]], with_grid=True) -> ChannelTables:
+    """Everything Channel.__init__ / Slicer derive (spectroModelChannel.py:27-108)."""
+    srf = get_srf(spec.det_pix_size, step_degree * 3600)               # spectroModel.py:67-70
+    origin_pix = (pix(spec.origin[0], step_degree), pix(spec.origin[1], step_degree))   # IFU.pix
+    pts = [(pix(p[0], step_degree), pix(p[1], step_degree)) for p in pointings]       # CoordList.pix
+    la = fov_local_axis(spec.alpha_width, 5 * step_degree, step_degree)
+    lb = fov_local_axis(spec.beta_width, 5 * step_degree, step_degree)
+    ws = wslice_of(wavel_axis, spec.wavel_axis[0], spec.wavel_axis[-1], 0.1)
+
+    bstep = beta_axis[1] - beta_axis[0]
+    sbw = spec.beta_width / spec.n_slit
+    npix_b = int(ceil(sbw / bstep))                                     # slicer.py:45-48
+    lstep = la[1] - la[0]
+    npix_a = int(ceil(spec.alpha_width / 2 / lstep)) - int(floor(-spec.alpha_width / 2 / lstep))  # :54-62
+    n_alpha_out = ceil(npix_a / srf)
+
+    slices = [_slit_slices(spec, s, la, lb, npix_a, npix_b, n_alpha_out) for s in range(spec.n_slit)]
+    weights = []
+    for s, sl in enumerate(slices):                                      # slicer.py:148-168
+        w = _fov_weight(_slit_local_fov(spec, s), sl, la, lb)
+        if s > 0 and slices[s - 1][3] - 1 != sl[2]:
+            w[:, 0] = 1
+        if s < spec.n_slit - 1 and sl[3] - 1 != slices[s + 1][2]:
+            w[:, -1] = 1
+        weights.append(w)
+
+    beta_in_slit = np.arange(0, npix_b) * bstep                         # spectroModelChannel.py:133-143
+    wpsf = spectral_psf(spec.grating_resolution, spec.wavel_axis,
+                        beta_in_slit - np.mean(beta_in_slit), wavel_axis[ws[0]:ws[1]],
+                        scale=(spec.wavel_axis[1] - spec.wavel_axis[0]) / spec.det_pix_size)
+
+    tab = ChannelTables(spec=spec, srf=srf, origin_pix=origin_pix, pointings=pts, wslice=ws,
+                        local_alpha_axis=la, local_beta_axis=lb,
+                        npix_slit_alpha_width=npix_a, npix_slit_beta_width=npix_b,
+                        n_alpha_out=n_alpha_out, slit_slices=slices, slit_weights=weights, wpsf=wpsf,
+                        oshape=(len(pts), spec.n_slit, len(spec.wavel_axis), n_alpha_out))
+    if with_grid:
+        for p in pts:
+            ga, gb = local2global(la, lb, spec.angle, (origin_pix[0] + p[0], origin_pix[1] + p[1]))
+            for k, (ax, v) in enumerate(((alpha_axis, ga), (beta_axis, gb))):
+                if not (np.all(ax[0] <= v) and np.all(v <= ax[-1])):   # cython_2D_interpolation.py:472-478
+                    raise ValueError("One of the requested xi is out of bounds in dimension %d" % k)
+            i0, y0 = find_indices(alpha_axis, ga.ravel())
+            i1, y1 = find_indices(beta_axis, gb.ravel())
+            tab.grid_idx.append((i0, i1))
+            tab.grid_frac.append((y0, y1))
+    return tab
+
+
+# ----------------------------------------------------------------------------
+# Channel operators (surfh/Models/spectroModelChannel.py)
+# ----------------------------------------------------------------------------
+def gridding(tab: ChannelTables, sub_cube, p):
+    """Channel.gridding (:158-177): bilinear cube -> rotated local grid."""
+    (i0, i1), (y0, y1) = tab.grid_idx[p], tab.grid_frac[p]
+    na, nb = len(tab.local_alpha_axis), len(tab.local_beta_axis)
+    return bilinear_apply(sub_cube, i0, i1, y0, y1).reshape(sub_cube.shape[0], na, nb)
+
+
+def gridding_t_ref(tab: ChannelTables, local_cube, p, alpha_axis, beta_axis):
+    """Channel.gridding_t (:180-199): the reference's *interpolating* back-projection
+    (bilinear local -> global, 0 outside).  NOT the transpose of ``gridding``."""
+    org = (tab.origin_pix[0] + tab.pointings[p][0], tab.origin_pix[1] + tab.pointings[p][1])
+    ca, cb = global2local(alpha_axis, beta_axis, tab.spec.angle, org)
+    la, lb = tab.local_alpha_axis, tab.local_beta_axis
+    i0, y0 = find_indices(la, ca.ravel())
+    i1, y1 = find_indices(lb, cb.ravel())
+    out = bilinear_apply(local_cube, i0, i1, y0, y1)
+    oob = (ca.ravel() < la[0]) | (ca.ravel() > la[-1]) | (cb.ravel() < lb[0]) | (cb.ravel() > lb[-1])
+    out[:, oob] = 0                                                 # cython_2D_interpolation.py:322-323
+    return out.reshape(local_cube.shape[0], len(alpha_axis), len(beta_axis))
+
+
+def gridding_T(tab: ChannelTables, local_cube, p, n_alpha, n_beta):
+    """Exact transpose of ``gridding`` (scatter-add of the same four weights)."""
+    (i0, i1), (y0, y1) = tab.grid_idx[p], tab.grid_frac[p]
+    L = local_cube.shape[0]
+    v = local_cube.reshape(L, -1)
+    out = np.zeros((L, n_alpha * n_beta))
+    for di, dj, w in ((0, 0, (1 - y0) * (1 - y1)), (0, 1, (1 - y0) * y1),
+                      (1, 0, y0 * (1 - y1)), (1, 1, y0 * y1)):
+        flat = (i0 + di) * n_beta + (i1 + dj)
+        for l in range(L):
+            out[l] += np.bincount(flat, weights=v[l] * w, minlength=n_alpha * n_beta)
+    return out.reshape(L, n_alpha, n_beta)
+
+
+def _box_filters(tab: ChannelTables):
+    """_otf_sr (:81-83) and decalf (:104-108) exactly as the reference forms them."""
+    shp = (len(tab.local_alpha_axis), len(tab.local_beta_axis))
+    otf_sr = ir2fr(np.ones((tab.srf, 1)), shp)[np.newaxis, ...]
+    decal = np.zeros(shp)
+    dsi = int((tab.srf - 1) / 2)
+    decal[-dsi, -0] = np.sqrt(shp[0] * shp[1])
+    return otf_sr, dft(decal)
+
+
+def box_sum_fft(tab: ChannelTables, local_cube):
+    """sum_cube (:220-223), done literally through the two FFTs."""
+    otf_sr, decalf = _box_filters(tab)
+    shp = local_cube.shape[-2:]
+    return idft(dft(local_cube) * (otf_sr * decalf), shp)
+
+
+def box_sum_fft_t(tab: ChannelTables, local_cube):
+    """:258-259"""
+    otf_sr, decalf = _box_filters(tab)
+    shp = local_cube.shape[-2:]
+    return idft(dft(local_cube) * otf_sr.conj() * decalf.conj(), shp)
+
+
+def box_sum_direct(tab: ChannelTables, local_cube):
+    """The same operator as a circular window sum: y[n] = sum_{j<srf} x[(n+j) mod na]."""
+    return sum(np.roll(local_cube, -j, axis=1) for j in range(tab.srf))
+
+
+def box_sum_direct_t(tab: ChannelTables, local_cube):
+    return sum(np.roll(local_cube, j, axis=1) for j in range(tab.srf))
+
+
+def slicing(tab: ChannelTables, cube, s):
+    """Slicer.slicing (slicer.py:64-68)."""
+    a0, a1, b0, b1 = tab.slit_slices[s]
+    return cube[:, a0:a1, b0:b1] * tab.slit_weights[s][np.newaxis]
+
+
+def slicing_t(tab: ChannelTables, slit, s, local_shape):
+    """Slicer.slicing_t (slicer.py:72-84)."""
+    out = np.zeros(local_shape)
+    a0, a1, b0, b1 = tab.slit_slices[s]
+    out[:, a0:a1, b0:b1] = slit * tab.slit_weights[s][np.newaxis]
+    return out
+
+
+def wblur_subsampling(sliced, wpsf):
+    """jax_utils.wblur_subSampling (:72-80): out[l',a] = sum_{l,b} W[l',l,b] x[l,a,b]."""
+    return np.einsum("klb,lab->ka", wpsf, sliced, optimize=True)
+
+
+def wblur_t(arr, wpsf):
+    """jax_utils.wblur_t (:83-91): x[l,a,b] = sum_l' y[l',a,b] W[l',l,b]."""
+    return np.einsum("kab,klb->lab", arr, wpsf, optimize=True)
+
+
+def channel_forward(tab: ChannelTables, blurred_cube, box="fft", stages=None):
+    """Channel.forward (:215-231)."""
+    out = np.zeros(tab.oshape)
+    sub = blurred_cube[tab.wslice[0]:tab.wslice[1]]
+    bs = box_sum_fft if box == "fft" else box_sum_direct
+    for p in range(len(tab.pointings)):
+        g = gridding(tab, sub, p)
+        sc = bs(tab, g)
+        if stages is not None:
+            stages.setdefault("gridded", []).append(g)
+            stages.setdefault("sum_cube", []).append(sc)
+        for s in range(tab.spec.n_slit):
+            sl = slicing(tab, sc, s)
+            out[p, s] = wblur_subsampling(sl, tab.wpsf)[:, : tab.oshape[3] * tab.srf: tab.srf]
+    return out.ravel()
+
+
+def channel_adjoint(tab: ChannelTables, y, alpha_axis, beta_axis, mode="exact", box="fft", stages=None):
+    """Channel.adjoint (:234-264).
+
+    mode="ref"   : reference behaviour, S back-projection by interpolation (gridding_t).
+    mode="exact" : true transpose of channel_forward (scatter-add S^T).
+    """
+    Lin = tab.wslice[1] - tab.wslice[0]
+    na, nb = len(tab.local_alpha_axis), len(tab.local_beta_axis)
+    a0, a1, b0, b1 = tab.slit_slices[0]
+    slit_shape = (Lin, a1 - a0, b1 - b0)                      # get_slit_shape_t (slicer.py:179-185)
+    y = y.reshape(tab.oshape)
+    inter = np.zeros((Lin, len(alpha_axis), len(beta_axis)))
+    bst = box_sum_fft_t if box == "fft" else box_sum_direct_t
+    for p in range(len(tab.pointings)):
+        local = np.zeros((Lin, na, nb))
+        for s in range(tab.spec.n_slit):
+            over = np.repeat(y[p, s][:, :, None], tab.npix_slit_beta_width, axis=2)
+            bts = np.zeros(slit_shape)
+            bts[:, : tab.oshape[3] * tab.srf: tab.srf, :] = wblur_t(over, tab.wpsf.conj())
+            local += slicing_t(tab, bts, s, (Lin, na, nb))
+        st = bst(tab, local)
+        if stages is not None:
+            stages.setdefault("local_cube", []).append(local)
+            stages.setdefault("sum_t", []).append(st)
+        if mode == "ref":
+            dg = gridding_t_ref(tab, st, p, alpha_axis, beta_axis)
+        else:
+            dg = gridding_T(tab, st, p, len(alpha_axis), len(beta_axis))
+        if stages is not None:
+            stages.setdefault("degridded", []).append(dg)
+        inter += dg
+    return inter
+
+
+# ----------------------------------------------------------------------------
+# Full operator (surfh/Models/spectroModel.py)
+# ----------------------------------------------------------------------------
+class OracleModel:
+    """spectroSigRLSCT (spectroModel.py:39-185) in float64."""
+
+    def __init__(self, sotf, templates, alpha_axis, beta_axis, wavelength_axis,
+                 specs: Sequence[ChannelSpec], step_degree, pointings, box="fft"):
+        self.sotf = np.asarray(sotf)
+        self.templates = None if templates is None else np.asarray(templates, dtype=np.float64)
+        self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
+        self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
+        self.wavelength_axis = np.asarray(wavelength_axis, dtype=np.float64)
+        self.box = box
+        self.channels = [build_channel(sp, self.alpha_axis, self.beta_axis, self.wavelength_axis,
+                                       step_degree, pointings[k]) for k, sp in enumerate(specs)]
+        n_lead = self.templates.shape[0] if self.templates is not None else len(self.wavelength_axis)
+        self.ishape = (n_lead, len(self.alpha_axis), len(self.beta_axis))
+        self.cube_shape = (len(self.wavelength_axis), len(self.alpha_axis), len(self.beta_axis))
+        self._idx = np.cumsum([0] + [int(np.prod(c.oshape)) for c in self.channels])
+        self.oshape = (int(self._idx[-1]),)
+
+    @property
+    def isize(self):
+        return int(np.prod(self.ishape))
+
+    @property
+    def osize(self):
+        return int(np.prod(self.oshape))
+
+    def blur(self, maps):
+        cube = lmm_maps2cube(maps, self.templates) if self.templates is not None else maps   # T  :161
+        return idft(dft(cube) * self.sotf, self.ishape[1:])                                  # C  :166
+
+    def forward(self, maps, stages=None):
+        blurred = self.blur(np.asarray(maps, dtype=np.float64).reshape(self.ishape))
+        if stages is not None:
+            stages["blurred"] = blurred
+        out = np.zeros(self.oshape)
+        for k, tab in enumerate(self.channels):                                              # :168-169
+            out[self._idx[k]: self._idx[k + 1]] = channel_forward(tab, blurred, self.box, stages)
+        return out
+
+    def _adjoint(self, y, mode, stages=None):
+        g = np.zeros(self.cube_shape)
+        for k, tab in enumerate(self.channels):                                              # :175-176
+            g[tab.wslice[0]:tab.wslice[1]] += channel_adjoint(
+                tab, np.asarray(y, dtype=np.float64)[self._idx[k]: self._idx[k + 1]],
+                self.alpha_axis, self.beta_axis, mode, self.box, stages)
+        if stages is not None:
+            stages["global_cube"] = g
+        bt = idft(dft(g) * self.sotf.conj(), self.ishape[1:])                                # :178
+        return lmm_cube2maps(bt, self.templates) if self.templates is not None else bt       # :181
+
+    def adjoint(self, y, stages=None):
+        """Exact transpose of ``forward`` (what CG and the dot-test use)."""
+        return self._adjoint(y, "exact", stages)
+
+    def adjoint_ref(self, y, stages=None):
+        """Reference behaviour (interpolating ``gridding_t``)."""
+        return self._adjoint(y, "ref", stages)
+
+    # aljabr.LinOp flat-vector forms used by dottest (test/sandbox_dottest.py:16-27)
+    def matvec(self, x):
+        return self.forward(x.reshape(self.ishape)).ravel()
+
+    def rmatvec(self, y):
+        return self.adjoint(y.reshape(self.oshape)).ravel()
+
+
+def dottest_gap(op, rng, num=1):
+    """|<A^T u, v> - <u, A v>| / |<u, A v>|  (aljabr.dottest restated, test/sandbox_dottest.py:16-27)."""
+    worst = 0.0
+    for _ in range(num):
+        v = rng.standard_normal(op.isize)
+        u = rng.standard_normal(op.osize)
+        left = np.vdot(op.rmatvec(u), v)
+        right = np.vdot(u, op.matvec(v))
+        worst = max(worst, abs(left - right) / abs(right))
+    return worst
+
+
+# ----------------------------------------------------------------------------
+# Priors and solver (surfh/Simulation/fusion_CT.py; qmm.lcg restated)
+# ----------------------------------------------------------------------------
+def diff_r(x):
+    """NpDiff_r.forward (fusion_CT.py:23-25)."""
+    return -np.diff(np.pad(x, ((0, 0), (1, 0), (0, 0)), "wrap"), axis=1)
+
+
+def diff_r_t(y):
+    """NpDiff_r.adjoint (:27-29)."""
+    return np.diff(np.pad(y, ((0, 0), (0, 1), (0, 0)), "wrap"), axis=1)
+
+
+def diff_c(x):
+    """NpDiff_c.forward (:38-40)."""
+    return -np.diff(np.pad(x, ((0, 0), (0, 0), (1, 0)), "wrap"), axis=2)
+
+
+def diff_c_t(y):
+    """NpDiff_c.adjoint (:42-43)."""
+    return np.diff(np.pad(y, ((0, 0), (0, 0), (0, 1)), "wrap"), axis=2)
+
+
+def normal_apply(op, x, mu, mu_reg):
+    """Q x = mu A^T A x + mu_reg (Dr^T Dr + Dc^T Dc) x  -- the three QuadObjective of fusion_CT.py:130-162."""
+    q = mu * op.adjoint(op.forward(x))
+    if mu_reg:
+        q = q + mu_reg * (diff_r_t(diff_r(x)) + diff_c_t(diff_c(x)))
+    return q
+
+
+def lcg(op, data, mu, mu_reg, x0, tol=1e-12, max_iter=10, refresh=50):
+    """Linear CG as ``qmm.lcg`` runs it (qmm 0.18.2 is absent: parity UNPINNED).
+
+    b = mu A^T y ; r = b - Qx ; d = r ; per iteration q = Qd, step = r.r / d.q,
+    x += step d, r refreshed from scratch every ``refresh`` iterations (incl. the
+    first) else r -= step q, d = r + (r'.r'/r.r) d, stop when sqrt(r.r) < size*tol.
+    ``grad_norm`` holds r.r, one entry before the loop and one per iteration.
+    Call site: surfh/Simulation/fusion_CT.py:194-225.
+    """
+    x = np.array(x0, dtype=np.float64, copy=True)
+    b = mu * op.adjoint(data)
+    r = b - normal_apply(op, x, mu, mu_reg)
+    d = r.copy()
+    grad_norm = [float(np.sum(r * r))]
+    nit = 0
+    for it in range(max_iter):
+        q = normal_apply(op, d, mu, mu_reg)
+        step = grad_norm[-1] / float(np.sum(d * q))
+        x += step * d
+        if refresh and it % refresh == 0:
+            r = b - normal_apply(op, x, mu, mu_reg)
+        else:
+            r -= step * q
+        grad_norm.append(float(np.sum(r * r)))
+        d = r + (grad_norm[-1] / grad_norm[-2]) * d
+        nit = it + 1
+        if np.sqrt(grad_norm[-1]) < x.size * tol:
+            break
+    return {"x": x, "grad_norm": grad_norm, "nit": nit}
+
+
+def crit_val(op, data, x, mu, mu_reg):
+    """QuadCriterion_MRS.get_crit_val (fusion_CT.py:242-265)."""
+    d = mu * np.sum((data - op.forward(x)) ** 2)
+    r = mu_reg * np.sum(diff_r(x) ** 2 + diff_c(x) ** 2)
+    return (d + r) / 2
+
+
+# ----------------------------------------------------------------------------
+# Synthetic inputs (formulas from test/global_variable_testing.py:227-234,
+# surfh/ToolsDir/utils.py:40-50, test/test_fw_ad.py:736-741)
+# ----------------------------------------------------------------------------
+def gaussian_psf(wavel_axis, step_arcsec, D=6.5):
+    x = np.linspace(-30, 30, 40).reshape((1, -1))
+    y = x.reshape((-1, 1))
+    psf = np.empty((len(wavel_axis), 40, 40))
+    for k, w in enumerate(wavel_axis):
+        sigma = ((w * 1e-6 / D) * 206265) / (step_arcsec * 2.354)
+        psf[k] = np.exp(-(x ** 2 + y ** 2) / (2 * sigma ** 2))
+    return psf / np.sum(psf, axis=(1, 2), keepdims=True)
+
+
+def synthetic_axes(n, step_degree):
+    ax = np.arange(n).astype(np.float64) * step_degree
+    return ax - np.mean(ax)
+
+
+def synthetic_templates(n_lambda):
+    lam = np.arange(n_lambda, dtype=np.float64)
+    c = (11.0, 15.0, 16.0, 17.0)
+    return np.stack([(0.2 + 0.1 * t) * lam + c[t] for t in range(4)])
+
+
+def dither4(det_pix_size_arcsec, slit_beta_width_deg):
+    da = (det_pix_size_arcsec / 3600) / 4
+    db = slit_beta_width_deg / 4
+    return [(da, db), (-da, db), (da, -db), (-da, -db)]

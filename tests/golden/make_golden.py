@@ -1,0 +1,176 @@
+"""Generate the golden vectors under tests/golden/ from the REAL reference.
+
+Run only in the build container:   python tests/golden/make_golden.py
+It imports the reference modules from /root/reference through
+``oracle/ref_harness.py`` (see that file for the exact list of aliases, the
+jax->python_utils mapping and the two restated third-party functions
+``udft.ir2fr`` / ``aljabr.LinOp``).  Every array written here was computed by
+reference code (surfh.Models.spectroModel.spectroSigRLSCT, .spectroModelChannel.Channel,
+.slicer.Slicer, .instru.*, surfh.ToolsDir.cythons_files) -- never by the oracle.
+The fixtures are data only: inputs are regenerated from seeds by tests/problems.py.
+"""
+from __future__ import annotations
+
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import ref_harness as rh  # noqa: E402
+import problems  # noqa: E402
+
+META = {
+    "reference": "sidiso/surfh @ 2025-02-04 (/root/reference)",
+    "restated_third_party": ["udft.ir2fr (udft 3.4.0)", "aljabr.LinOp (aljabr 0.4.0)"],
+    "jax_utils_mapped_to": "surfh/ToolsDir/python_utils.py (float64)",
+}
+
+
+def ref_model(ns, cfg):
+    I = ns.instru
+    ifus = [rh.make_ifu(ns, s) for s in cfg["specs"]]
+    pls = [I.CoordList([I.Coord(a, b) for a, b in pts]).pix(cfg["step_deg"]) for pts in cfg["pointings"]]
+    return ns.model.spectroSigRLSCT(cfg["sotf"], cfg["templates"], cfg["alpha_axis"], cfg["beta_axis"],
+                                    cfg["wavel"], ifus, cfg["step_deg"], pls)
+
+
+def channel_stages(ns, ch, blurred, lam_sel):
+    """Re-run Channel.forward's loop body (spectroModelChannel.py:215-231) keeping intermediates."""
+    ju = sys.modules["surfh.ToolsDir.jax_utils"]
+    out = {}
+    for p, pointing in enumerate(ch.pointings):
+        g = ch.gridding(blurred[ch.wslice], pointing)
+        sc = ju.idft(ju.dft_mult(g, ch._otf_sr * ch.decalf), ch.local_im_shape)
+        out[f"gridded_p{p}"] = np.asarray(g)[lam_sel]
+        out[f"sum_cube_p{p}"] = np.asarray(sc)[lam_sel]
+    return out
+
+
+def channel_tables(ns, ch, prefix):
+    d = {}
+    sl = ch.slicer
+    n = ch.instr.n_slit
+    slices = [sl.get_slit_slices(s) for s in range(n)]
+    d[prefix + "slit_slices"] = np.array([[s[0].start, s[0].stop, s[1].start, s[1].stop] for s in slices], dtype=np.int64)
+    ws = [sl.get_slit_weights(s, slices[s])[0] for s in range(n)]
+    d[prefix + "slit_w_first"] = np.array([w[0, 0] for w in ws])
+    d[prefix + "slit_w_last"] = np.array([w[0, -1] for w in ws])
+    d[prefix + "slit_w_interior_is_one"] = np.array([bool(np.all(w[:, 1:-1] == 1) and np.all(w == w[0:1])) for w in ws])
+    d[prefix + "srf"] = np.int64(ch.srf)
+    d[prefix + "wslice"] = np.array([ch.wslice.start, ch.wslice.stop], dtype=np.int64)
+    d[prefix + "local_alpha_axis"] = ch.local_alpha_axis
+    d[prefix + "local_beta_axis"] = ch.local_beta_axis
+    d[prefix + "npix_ab"] = np.array([sl.npix_slit_alpha_width, sl.npix_slit_beta_width], dtype=np.int64)
+    d[prefix + "oshape"] = np.array(ch.oshape, dtype=np.int64)
+    d[prefix + "pointings_pix"] = np.array([[c.alpha, c.beta] for c in ch.pointings])
+    d[prefix + "origin_pix"] = np.array([ch.instr.fov.origin.alpha, ch.instr.fov.origin.beta])
+    return d
+
+
+def bilinear_tables(ns, ch, alpha_axis, beta_axis, p):
+    """find_indices on the local->global coordinates (cythons_files.pyx:109-154)."""
+    ga, gb = (ch.instr.fov + ch.pointings[p]).local2global(ch.local_alpha_axis, ch.local_beta_axis)
+    xi = np.vstack([ga.ravel(), gb.ravel()])
+    idx, frac = ns.cythons_files.find_indices((alpha_axis, beta_axis), xi)
+    return np.asarray(idx), np.asarray(frac)
+
+
+def main():
+    ns = rh.load()
+    # ---------------- config 1: full chain ----------------
+    cfg = problems.config1()
+    rm = ref_model(ns, cfg)
+    ch = rm.channels[0]
+    maps = cfg["maps"]
+    y = rm.forward(maps)
+    u = np.random.default_rng(1).standard_normal(y.size)
+    adj = rm.adjoint(u)
+    lam_sel = np.array([0, 37, 126])
+    ju = sys.modules["surfh.ToolsDir.jax_utils"]
+    cube = ju.lmm_maps2cube(maps, cfg["templates"]).reshape(rm.cube_shape)
+    blurred = ju.idft(ju.dft(cube) * rm.sotf, rm.imshape)
+    d = {"y": y, "u_seed": np.int64(1), "adjoint_ref": adj, "lam_sel": lam_sel,
+         "blurred_sel": np.asarray(blurred)[lam_sel], "wpsf": ch.wpsf}
+    d.update(channel_stages(ns, ch, np.asarray(blurred), lam_sel))
+    d.update(channel_tables(ns, ch, "c0_"))
+    for p in range(len(ch.pointings)):
+        idx, frac = bilinear_tables(ns, ch, cfg["alpha_axis"], cfg["beta_axis"], p)
+        d[f"bil_idx_p{p}"] = idx.astype(np.int32)
+        d[f"bil_frac_p{p}"] = frac
+    # adjoint-side intermediates of the reference for pointing 0 (spectroModelChannel.py:234-264)
+    yin = u.reshape(ch.oshape)
+    Lin = ch.wslice.stop - ch.wslice.start
+    local = np.zeros((Lin,) + ch.local_im_shape)
+    for s in range(ch.instr.n_slit):
+        over = np.repeat(yin[0, s][:, :, None], ch.slicer.npix_slit_beta_width, axis=2)
+        bts = np.zeros(ch.slicer.get_slit_shape_t())
+        bts[:, : ch.oshape[3] * ch.srf: ch.srf, :] = ju.wblur_t(over, ch.wpsf.conj())
+        local += ch.slicer.slicing_t(bts, s, (Lin,) + ch.local_im_shape)
+    sum_t = ju.idft(ju.dft(local) * ch._otf_sr.conj() * ch.decalf.conj(), ch.local_im_shape)
+    dg = ch.gridding_t(np.array(sum_t, dtype=np.float64), ch.pointings[0])
+    d["adj_local_cube_p0_sel"] = local[lam_sel]
+    d["adj_sum_t_p0_sel"] = np.asarray(sum_t)[lam_sel]
+    d["adj_degridded_ref_p0_sel"] = np.asarray(dg)[lam_sel]
+    d["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, "config1_chain.npz"), **d)
+    print("config1: ||y|| =", np.linalg.norm(y), "oshape", ch.oshape)
+
+    # ---------------- two overlapping channels ----------------
+    cfg2 = problems.two_channel_small()
+    rm2 = ref_model(ns, cfg2)
+    y2 = rm2.forward(cfg2["maps"])
+    u2 = np.random.default_rng(2).standard_normal(y2.size)
+    d2 = {"y": y2, "u_seed": np.int64(2), "adjoint_ref": rm2.adjoint(u2), "idx": np.asarray(rm2._idx, dtype=np.int64)}
+    for k, c in enumerate(rm2.channels):
+        d2.update(channel_tables(ns, c, f"c{k}_"))
+    d2["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, "two_channel.npz"), **d2)
+    print("two_channel: ||y|| =", np.linalg.norm(y2), "idx", rm2._idx)
+
+    # ---------------- geometry of the 12 real bands at N=251 ----------------
+    N = 251
+    ax = np.arange(N).astype(np.float64) * problems.STEP_DEG
+    ax -= np.mean(ax)
+    gv = ns.global_variables
+    g = {}
+    axes = {
+        "cfg2": np.linspace(7.41, 8.87, 1024),
+        "cfg3": np.linspace(gv.wavelength_1c[0], gv.wavelength_2c[-1], 4000),
+        "cfg4": np.linspace(4.90, 28.70, 8000),
+    }
+    for k, v in axes.items():
+        g["axis_" + k] = np.array([v[0], v[-1], len(v)])
+    I = ns.instru
+    for name in problems.BANDS:
+        wa = getattr(gv, "wavelength_" + name)
+        g[f"{name}_wavel"] = wa
+        spec = problems.band_spec(name, wavel_axis=wa)
+        ifu = rh.make_ifu(ns, spec)
+        pts = problems.orc.dither4(spec.det_pix_size, spec.beta_width / spec.n_slit)
+        pl = I.CoordList([I.Coord(a, b) for a, b in pts])
+        c = ns.channel.Channel(ifu, ax, ax, axes["cfg4"], I.get_srf([spec.det_pix_size], problems.STEP)[0], pl, problems.STEP_DEG)
+        g.update(channel_tables(ns, c, f"{name}_"))
+        g[f"{name}_wpsf_sample"] = c.wpsf[::97, ::53, :]
+        g[f"{name}_wpsf_shape"] = np.array(c.wpsf.shape, dtype=np.int64)
+        g[f"{name}_wpsf_rowsum_minmax"] = np.array([c.wpsf.sum(axis=(1, 2)).min(), c.wpsf.sum(axis=(1, 2)).max()])
+        for k in ("cfg2", "cfg3"):
+            ws = c.instr.wslice(axes[k], 0.1)
+            g[f"{name}_wslice_{k}"] = np.array([ws.start, ws.stop], dtype=np.int64)
+        if name == "2a":
+            for p in range(4):
+                idx, frac = bilinear_tables(ns, c, ax, ax, p)
+                g[f"2a_bil_idx_p{p}"] = idx[:, ::5].astype(np.int32)
+                g[f"2a_bil_frac_p{p}"] = frac[:, ::5]
+        print(name, "srf", c.srf, "local", c.local_im_shape, "oshape", c.oshape, "wslice", c.wslice)
+    g["meta"] = np.array(json.dumps(META))
+    np.savez_compressed(os.path.join(HERE, "bands_geometry.npz"), **g)
+
+
+if __name__ == "__main__":
+    main()
