@@ -1,0 +1,142 @@
+/* surfh_amd -- C ABI of the MI355X-native surfh hot path.
+ *
+ * One `surfh_plan` = one GPU + one HIP stream + the set of MRS channels that GPU
+ * owns.  It is the drop-in replacement for the arithmetic behind
+ *   spectroSigRLSCT.forward / .adjoint     (surfh/Models/spectroModel.py:158-185)
+ *   Channel.forward / .adjoint             (surfh/Models/spectroModelChannel.py:215-264)
+ *   Slicer.slicing / slicing_t             (surfh/Models/slicer.py:64-84)
+ *   jax_utils.{lmm_*, dft, idft, dft_mult, wblur_subSampling, wblur_t}
+ *                                          (surfh/ToolsDir/jax_utils.py:10-91)
+ *   cythons_files.solve_2D_hypercube       (surfh/ToolsDir/cythons_files.pyx:163-193)
+ *   NpDiff_r / NpDiff_c + qmm.lcg loop     (surfh/Simulation/fusion_CT.py:16-43,194-225)
+ * All file:line citations are relative to the reference tree (sidiso/surfh @ 2025-02-04).
+ *
+ * Conventions
+ *   - plain C, no torch types.  Host pointers unless the name ends in `_dev`.
+ *   - every function returns 0 on success, non-zero on error; the message is
+ *     available from surfh_last_error() (thread-local, valid until the next call).
+ *   - the geometry tables are produced by the host side (surfh_amd/geometry.py),
+ *     which restates instru.py / slicer.py; the library only consumes them.
+ *   - arithmetic type: fp32 on device (fp32-input MFMA, exact fp32 products);
+ *     inner products of the CG loop accumulate in fp64.
+ */
+#ifndef SURFH_AMD_H
+#define SURFH_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct surfh_plan surfh_plan;
+
+/* One MRS channel (what Channel.__init__ + Slicer derive; spectroModelChannel.py:27-108). */
+typedef struct {
+    int32_t wslice_start, wslice_stop; /* IFU.wslice on the cube axis (instru.py:649-658)            */
+    int32_t n_pointings;               /* P                                                         */
+    int32_t n_slit;                    /* S                                                         */
+    int32_t n_lambda_out;              /* Ldet = len(instr.wavel_axis)                              */
+    int32_t n_alpha_out;               /* ceil(npix_slit_alpha_width / srf)                         */
+    int32_t srf;                       /* super-resolution factor (instru.py:67-84)                 */
+    int32_t na, nb;                    /* local grid (len(local_alpha_axis), len(local_beta_axis))  */
+    int32_t alpha0;                    /* first local alpha row of the slit window (slicer.py:118)  */
+    int32_t n_alpha_slit;              /* length of the alpha window                                */
+    int32_t n_beta_slit;               /* npix_slit_beta_width (slicer.py:45-48)                    */
+    const int32_t *slit_beta0;         /* [S]    first local beta column of each slit               */
+    const double *slit_weights;        /* [S][n_beta_slit] beta-edge weights (slicer.py:148-168)    */
+    const int32_t *grid_i0;            /* [P][na*nb] lower alpha index (cythons_files.pyx:109-154)  */
+    const int32_t *grid_i1;            /* [P][na*nb] lower beta index                               */
+    const double *grid_y0;             /* [P][na*nb] normalised alpha distance                      */
+    const double *grid_y1;             /* [P][na*nb] normalised beta distance                       */
+    const double *wpsf;                /* [Ldet][Lin][n_beta_slit] spectral PSF (instru.py:499-572) */
+    /* reference-compatible back-interpolation tables for surfh_adjoint_ref (gridding_t,
+       spectroModelChannel.py:180-199); may be NULL if adjoint_ref is never called.               */
+    const int32_t *gt_i0;              /* [P][Na*Nb] lower local alpha index                        */
+    const int32_t *gt_i1;              /* [P][Na*Nb] lower local beta index                         */
+    const double *gt_y0;               /* [P][Na*Nb]                                                */
+    const double *gt_y1;               /* [P][Na*Nb]                                                */
+    const uint8_t *gt_inside;          /* [P][Na*Nb] 1 if the global pixel falls inside the local grid */
+} surfh_channel_desc;
+
+typedef struct {
+    int32_t n_alpha, n_beta;           /* cube spatial shape                                        */
+    int32_t n_lambda;                  /* cube planes Lc                                            */
+    int32_t n_templates;               /* T; 0 => no LMM (input is the cube itself)                 */
+    const double *templates;           /* [T][Lc] or NULL                                           */
+    const double *sotf;                /* [Lc][n_alpha][n_beta/2+1] complex128 interleaved (re,im)  */
+    int32_t n_channels;
+    const surfh_channel_desc *channels;
+    int32_t device;                    /* HIP device ordinal                                        */
+    void *stream;                      /* hipStream_t to run on, or NULL: the plan creates its own  */
+    int32_t split_k_forward;           /* 0 = auto                                                  */
+} surfh_config;
+
+const char *surfh_last_error(void);
+int surfh_version(void);
+
+int surfh_plan_create(const surfh_config *cfg, surfh_plan **out);
+int surfh_plan_destroy(surfh_plan *plan);
+
+/* sizes: isize = T*Na*Nb (or Lc*Na*Nb without LMM), osize = sum_c P*S*Ldet*alpha_out */
+int64_t surfh_isize(const surfh_plan *plan);
+int64_t surfh_osize(const surfh_plan *plan);
+void *surfh_stream(const surfh_plan *plan);
+
+/* y = A x      (spectroSigRLSCT.forward, spectroModel.py:158-170)                   */
+int surfh_forward(surfh_plan *plan, const float *maps, float *y);
+/* x = A^T y    exact transpose of surfh_forward (what CG and the dot-test use)      */
+int surfh_adjoint(surfh_plan *plan, const float *y, float *maps);
+/* x = reference adjoint with the interpolating gridding_t (spectroModel.py:173-185) */
+int surfh_adjoint_ref(surfh_plan *plan, const float *y, float *maps);
+/* out = A^T A x                                                                      */
+int surfh_fwadj(surfh_plan *plan, const float *x, float *out);
+
+/* device-pointer, asynchronous variants (run on the plan's stream) */
+int surfh_forward_dev(surfh_plan *plan, const float *maps_dev, float *y_dev);
+int surfh_adjoint_dev(surfh_plan *plan, const float *y_dev, float *maps_dev);
+int surfh_adjoint_ref_dev(surfh_plan *plan, const float *y_dev, float *maps_dev);
+int surfh_fwadj_dev(surfh_plan *plan, const float *x_dev, float *out_dev);
+
+/* ---- regularised least squares by linear CG (fusion_CT.py:118-238 + qmm.lcg) ----
+ * minimises  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2).
+ * grad_norm receives r.r (max_iter+1 doubles), nit the iterations done.             */
+int surfh_cg(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0,
+             int32_t max_iter, double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
+
+/* CG building blocks on device vectors, for the multi-GPU driver (one plan per rank,
+ * RCCL all-reduce of `q` between surfh_normal_dev and surfh_cg_step_dev).            */
+int surfh_normal_dev(surfh_plan *plan, const float *d_dev, float *q_dev, double mu);          /* q  = mu A^T A d   */
+int surfh_prior_add_dev(surfh_plan *plan, const float *d_dev, float *q_dev, double mu_reg);   /* q += mu_reg L d   */
+int surfh_dot_dev(surfh_plan *plan, const float *a_dev, const float *b_dev, int64_t n, double *out_host);
+/* x += s d ; r -= s q ; returns r.r  (s = rr / d.q computed on device from rr_in)    */
+int surfh_cg_step_dev(surfh_plan *plan, float *x_dev, float *r_dev, const float *d_dev,
+                      const float *q_dev, int64_t n, double rr_in, double *rr_out_host);
+/* d = r + beta d */
+int surfh_cg_dir_dev(surfh_plan *plan, float *d_dev, const float *r_dev, int64_t n, double beta);
+/* r = b - q */
+int surfh_residual_dev(surfh_plan *plan, float *r_dev, const float *b_dev, const float *q_dev, int64_t n);
+
+/* ---- instrumentation ---- */
+/* enable/disable per-kernel HIP-event timing on the plan's stream */
+int surfh_profile_enable(surfh_plan *plan, int32_t on);
+/* number of distinct kernel names timed since the last reset */
+int32_t surfh_profile_count(surfh_plan *plan);
+/* i-th entry: name, launches, total milliseconds */
+int surfh_profile_get(surfh_plan *plan, int32_t i, const char **name, int64_t *launches, double *ms);
+int surfh_profile_reset(surfh_plan *plan);
+
+/* copy an internal buffer to the host for stage-level parity tests.
+ * which: "blurred" [Lown][NaP][NbP], "xs:<c>" [Kp][Np], "gcube" [Lown][NaP][NbP], ...
+ * returns the number of floats written (<= capacity) or a negative error.            */
+int64_t surfh_debug_copy(surfh_plan *plan, const char *which, float *out, int64_t capacity);
+int surfh_debug_dims(surfh_plan *plan, const char *which, int64_t dims[4]);
+
+/* stand-alone fp32 MFMA GEMM self-test hook: C[M][N] = A[M][K] B[K][N] (host buffers) */
+int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split_k,
+                        const float *A, const float *B, float *C);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SURFH_AMD_H */

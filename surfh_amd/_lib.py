@@ -1,0 +1,113 @@
+"""ctypes binding of the C ABI in include/surfh_amd.h (libsurfh_amd.so, built in-tree by
+``__graft_entry__.build()``).  There is no CPU fallback: if the library is missing or a
+call fails, an exception is raised."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsurfh_amd.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+c_int32_p = C.POINTER(C.c_int32)
+c_uint8_p = C.POINTER(C.c_uint8)
+
+
+class ChannelDesc(C.Structure):
+    _fields_ = [
+        ("wslice_start", C.c_int32), ("wslice_stop", C.c_int32),
+        ("n_pointings", C.c_int32), ("n_slit", C.c_int32), ("n_lambda_out", C.c_int32),
+        ("n_alpha_out", C.c_int32), ("srf", C.c_int32), ("na", C.c_int32), ("nb", C.c_int32),
+        ("alpha0", C.c_int32), ("n_alpha_slit", C.c_int32), ("n_beta_slit", C.c_int32),
+        ("slit_beta0", c_int32_p), ("slit_weights", c_double_p),
+        ("grid_i0", c_int32_p), ("grid_i1", c_int32_p), ("grid_y0", c_double_p), ("grid_y1", c_double_p),
+        ("wpsf", c_double_p),
+        ("gt_i0", c_int32_p), ("gt_i1", c_int32_p), ("gt_y0", c_double_p), ("gt_y1", c_double_p),
+        ("gt_inside", c_uint8_p),
+    ]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("n_alpha", C.c_int32), ("n_beta", C.c_int32), ("n_lambda", C.c_int32), ("n_templates", C.c_int32),
+        ("templates", c_double_p), ("sotf", c_double_p),
+        ("n_channels", C.c_int32), ("channels", C.POINTER(ChannelDesc)),
+        ("device", C.c_int32), ("stream", C.c_void_p), ("split_k_forward", C.c_int32),
+    ]
+
+
+EXPORTS = [
+    "surfh_last_error", "surfh_version", "surfh_plan_create", "surfh_plan_destroy", "surfh_isize", "surfh_osize",
+    "surfh_stream", "surfh_forward", "surfh_adjoint", "surfh_adjoint_ref", "surfh_fwadj", "surfh_forward_dev",
+    "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev", "surfh_cg", "surfh_normal_dev",
+    "surfh_prior_add_dev", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_residual_dev",
+    "surfh_profile_enable", "surfh_profile_count", "surfh_profile_get", "surfh_profile_reset", "surfh_debug_copy",
+    "surfh_debug_dims", "surfh_gemm_selftest",
+]
+
+_lib = None
+
+
+def load():
+    """Load libsurfh_amd.so and declare the prototypes.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP path has no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.surfh_last_error.restype = C.c_char_p
+    L.surfh_version.restype = C.c_int
+    L.surfh_plan_create.argtypes = [C.POINTER(Config), C.POINTER(vp)]
+    L.surfh_plan_destroy.argtypes = [vp]
+    L.surfh_isize.argtypes = [vp]; L.surfh_isize.restype = C.c_int64
+    L.surfh_osize.argtypes = [vp]; L.surfh_osize.restype = C.c_int64
+    L.surfh_stream.argtypes = [vp]; L.surfh_stream.restype = vp
+    for n in ("surfh_forward", "surfh_adjoint", "surfh_adjoint_ref", "surfh_fwadj"):
+        getattr(L, n).argtypes = [vp, c_float_p, c_float_p]
+    for n in ("surfh_forward_dev", "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev"):
+        getattr(L, n).argtypes = [vp, vp, vp]
+    L.surfh_cg.argtypes = [vp, c_float_p, C.c_double, C.c_double, c_float_p, C.c_int32, C.c_double, C.c_int32,
+                           c_float_p, c_double_p, c_int32_p]
+    L.surfh_normal_dev.argtypes = [vp, vp, vp, C.c_double]
+    L.surfh_prior_add_dev.argtypes = [vp, vp, vp, C.c_double]
+    L.surfh_dot_dev.argtypes = [vp, vp, vp, C.c_int64, c_double_p]
+    L.surfh_cg_step_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_double, c_double_p]
+    L.surfh_cg_dir_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_double]
+    L.surfh_residual_dev.argtypes = [vp, vp, vp, vp, C.c_int64]
+    L.surfh_profile_enable.argtypes = [vp, C.c_int32]
+    L.surfh_profile_count.argtypes = [vp]; L.surfh_profile_count.restype = C.c_int32
+    L.surfh_profile_get.argtypes = [vp, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), c_double_p]
+    L.surfh_profile_reset.argtypes = [vp]
+    L.surfh_debug_copy.argtypes = [vp, C.c_char_p, c_float_p, C.c_int64]; L.surfh_debug_copy.restype = C.c_int64
+    L.surfh_debug_dims.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.surfh_gemm_selftest.argtypes = [C.c_int32] * 5 + [c_float_p, c_float_p, c_float_p]
+    _lib = L
+    return L
+
+
+def check(rc: int, exc=RuntimeError):
+    if rc != 0:
+        raise exc(load().surfh_last_error().decode("utf-8", "replace"))
+
+
+def fptr(a: np.ndarray):
+    return a.ctypes.data_as(c_float_p)
+
+
+def dptr(a: np.ndarray):
+    return a.ctypes.data_as(c_double_p)
+
+
+def iptr(a: np.ndarray):
+    return a.ctypes.data_as(c_int32_p)
+
+
+def u8ptr(a: np.ndarray):
+    return a.ctypes.data_as(c_uint8_p)

@@ -1,0 +1,29 @@
+// fp32-input MFMA GEMM used by every dense contraction on the path:
+//   R / R^T  (wblur_subSampling / wblur_t, surfh/ToolsDir/jax_utils.py:72-91)
+//   the 2-D DFTs of the C stage written as real matrix products (jax_utils.py:30-41)
+// C[b] (MxN, row-major) = A[b] (MxK, row-major) * B[b] (KxN, row-major), all fp32,
+// v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct GemmArgs {
+    // A operand: element (m,k) = (k < ksplitA ? A0[m*lda + k] : A1[m*lda + k - ksplitA])
+    const float *A0 = nullptr, *A1 = nullptr;
+    int ksplitA = 1 << 30;
+    long lda = 0, sA = 0;   // leading dimension, batch stride (elements)
+    // B operand: element (k,n) = (k < ksplitB ? B0[k*ldb + n] : B1[(k-ksplitB)*ldb + n])
+    const float *B0 = nullptr, *B1 = nullptr;
+    int ksplitB = 1 << 30;
+    long ldb = 0, sB = 0;
+    float *C = nullptr;
+    long ldc = 0, sC = 0;
+    int M = 0, N = 0, K = 0;       // multiples of 64 (M,N) and 16 (K)
+    int batch = 1;
+    int splitK = 1;                // >1: K is cut in splitK slabs, slab s is written to C + s*sCsplit
+    long sCsplit = 0;
+    int accumulate = 0;            // 1: C += A*B (only with splitK==1)
+};
+
+// returns hipError_t as int; name is used by the profiler
+int launch_gemm_f32(hipStream_t stream, const GemmArgs &g);

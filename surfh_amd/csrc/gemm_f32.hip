@@ -1,0 +1,156 @@
+// fp32 MFMA GEMM for gfx950 (see gemm_f32.h).  One workgroup = 4 waves (2x2),
+// block tile BM x BN x 16, each wave owns a (BM/2) x (BN/2) sub-tile made of
+// 32x32 MFMA tiles.  v_mfma_f32_32x32x2_f32 operand maps (lane l):
+//   A[i = l&31][k = l>>5],  B[k = l>>5][j = l&31],
+//   D reg r -> row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31.
+// The contraction order inside a K tile is permuted so that each lane fetches its
+// A values with one ds_read_b128: lanes with l>>5 == h read k = 8q+4h .. 8q+4h+3,
+// MFMA step (q,m) therefore contracts the k pair {8q+m, 8q+4+m}; the B operand is
+// read from the matching rows.
+#include "gemm_f32.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BK = 16;
+constexpr int ASTR = 20;   // LDS row stride of the A tile (floats): conflict-free ds_read_b128
+
+template <int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int MT = BM / 64;          // 32x32 tiles per wave along M
+    constexpr int NT = BN / 64;          // 32x32 tiles per wave along N
+    constexpr int A_LD = BM / 64;        // float4 per thread per A tile
+    constexpr int B_LD = BN / 64;        // float4 per thread per B tile
+    constexpr int B_TPR = BN / 4;        // threads per B row
+    constexpr int B_RPP = 256 / B_TPR;   // B rows per pass
+
+    __shared__ __attribute__((aligned(16))) float As[2][BM * ASTR];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK * BN];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, h = lane >> 5;
+
+    const int tilesN = g.N / BN;
+    const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+    const int b = blockIdx.z / g.splitK, sk = blockIdx.z % g.splitK;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int Kper = g.K / g.splitK;
+    const int kbeg = sk * Kper;
+    const int nk = Kper / BK;
+
+    const int ar = tid >> 2, ac = (tid & 3) * 4;
+    const int br = tid / B_TPR, bc = (tid % B_TPR) * 4;
+
+    const float *Ab0 = g.A0 + (long)b * g.sA;
+    const float *Ab1 = g.A1 ? g.A1 + (long)b * g.sA : nullptr;
+    const float *Bb0 = g.B0 + (long)b * g.sB;
+    const float *Bb1 = g.B1 ? g.B1 + (long)b * g.sB : nullptr;
+
+    float4 ra[A_LD], rb[B_LD];
+
+#define GEMM_GLOAD(kt_)                                                                              \
+    {                                                                                                \
+        const int k0 = kbeg + (kt_) * BK;                                                            \
+        const float *Ap = (k0 < g.ksplitA) ? Ab0 + k0 : Ab1 + (k0 - g.ksplitA);                      \
+        _Pragma("unroll") for (int u = 0; u < A_LD; ++u) ra[u] =                                     \
+            *reinterpret_cast<const float4 *>(Ap + (long)(m0 + ar + 64 * u) * g.lda + ac);           \
+        const float *Bp =                                                                            \
+            (k0 < g.ksplitB) ? Bb0 + (long)k0 * g.ldb : Bb1 + (long)(k0 - g.ksplitB) * g.ldb;        \
+        _Pragma("unroll") for (int u = 0; u < B_LD; ++u) rb[u] =                                     \
+            *reinterpret_cast<const float4 *>(Bp + (long)(br + B_RPP * u) * g.ldb + n0 + bc);        \
+    }
+#define GEMM_LSTORE(buf_)                                                                            \
+    {                                                                                                \
+        _Pragma("unroll") for (int u = 0; u < A_LD; ++u)                                             \
+            *reinterpret_cast<float4 *>(&As[buf_][(ar + 64 * u) * ASTR + ac]) = ra[u];               \
+        _Pragma("unroll") for (int u = 0; u < B_LD; ++u)                                             \
+            *reinterpret_cast<float4 *>(&Bs[buf_][(br + B_RPP * u) * BN + bc]) = rb[u];              \
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    GEMM_GLOAD(0);
+    GEMM_LSTORE(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        // the last iteration re-fetches the last tile (harmless) so the loop body is branch-free
+        GEMM_GLOAD((kt + 1 < nk) ? kt + 1 : kt);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 a[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                a[mt] = *reinterpret_cast<const float4 *>(
+                    &As[buf][(wm * (BM / 2) + mt * 32 + l31) * ASTR + 8 * q + 4 * h]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float bv[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    bv[nt] = Bs[buf][(8 * q + 4 * h + m) * BN + wn * (BN / 2) + nt * 32 + l31];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float av = (m == 0) ? a[mt].x : (m == 1) ? a[mt].y : (m == 2) ? a[mt].z : a[mt].w;
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt)
+                        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[nt], acc[mt][nt], 0, 0, 0);
+                }
+            }
+        }
+        GEMM_LSTORE(buf ^ 1);
+        __syncthreads();
+    }
+
+    float *Cb = g.C + (long)b * g.sC + (long)sk * g.sCsplit;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + wn * (BN / 2) + nt * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * (BM / 2) + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float *p = Cb + (long)row * g.ldc + col;
+                if (g.accumulate)
+                    *p += acc[mt][nt][r];
+                else
+                    *p = acc[mt][nt][r];
+            }
+        }
+}
+
+#undef GEMM_GLOAD
+#undef GEMM_LSTORE
+}  // namespace
+
+int launch_gemm_f32(hipStream_t stream, const GemmArgs &g) {
+    if (g.M % 64 || g.N % 64 || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1) return (int)hipErrorInvalidValue;
+    if (g.ksplitA != (1 << 30) && g.ksplitA % BK) return (int)hipErrorInvalidValue;
+    if (g.ksplitB != (1 << 30) && g.ksplitB % BK) return (int)hipErrorInvalidValue;
+    if (g.splitK > 1 && g.accumulate) return (int)hipErrorInvalidValue;
+    // K slabs must not straddle a ksplit boundary inside a K tile: guaranteed by the %BK checks above
+    const bool m128 = (g.M % 128 == 0), n128 = (g.N % 128 == 0);
+    const int bm = m128 ? 128 : 64, bn = n128 ? 128 : 64;
+    dim3 grid((g.M / bm) * (g.N / bn), 1, g.batch * g.splitK), block(256);
+    if (m128 && n128)
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 128>), grid, block, 0, stream, g);
+    else if (m128)
+        hipLaunchKernelGGL((gemm_f32_kernel<128, 64>), grid, block, 0, stream, g);
+    else if (n128)
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 128>), grid, block, 0, stream, g);
+    else
+        hipLaunchKernelGGL((gemm_f32_kernel<64, 64>), grid, block, 0, stream, g);
+    return (int)hipGetLastError();
+}

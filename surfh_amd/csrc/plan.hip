@@ -1,0 +1,947 @@
+// Host side of the C ABI (include/surfh_amd.h): plan construction, table building,
+// the forward / adjoint pipelines and the CG loop.  All device work goes through
+// gemm_f32.hip and kernels.hip on one HIP stream.
+//
+// Pipeline (per plan = per GPU), reference citations relative to /root/reference:
+//   forward  (spectroModel.py:158-170, spectroModelChannel.py:215-231)
+//     maps --pad--> rfft2 (2 GEMMs) --> mhat[T]
+//     spec[l]   = sotf[l] * sum_t tpl[t,l] mhat[t]                    (T and C fused, Fourier domain)
+//     blurred   = irfft2(spec)  (2 GEMMs per plane)
+//     per channel:  Xs[(l,b'),(p,s,a)] = G * blurred[l]               (S + box-sum + L + decimation, ELL gather)
+//                   y[(p,s),l',a] = sum_{(l,b')} W[l',(l,b')] Xs      (R + beta-sum, one GEMM, split-K)
+//   adjoint  (spectroModel.py:173-185, spectroModelChannel.py:234-264): the transposes, in reverse.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/surfh_amd.h"
+#include "gemm_f32.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return 1;
+}
+
+#define HIP_OK(expr)                                                                              \
+    do {                                                                                          \
+        hipError_t e_ = (expr);                                                                   \
+        if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define LAUNCH_OK(expr)                                                                           \
+    do {                                                                                          \
+        int e_ = (expr);                                                                          \
+        if (e_ != 0) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString((hipError_t)e_), __FILE__, __LINE__); \
+    } while (0)
+
+inline int pad64(int n) { return (n + 63) / 64 * 64; }
+
+struct DevEll {
+    EllTable t;
+    int32_t *cnt = nullptr, *col = nullptr, *dst = nullptr;
+    float *val = nullptr;
+};
+
+struct Channel {
+    int ws0 = 0, ws1 = 0, Lin = 0, P = 0, S = 0, Ldet = 0, aout = 0, srf = 0, na = 0, nb = 0, alpha0 = 0, nas = 0,
+        nbs = 0;
+    int KP = 0, NP = 0, LdetP = 0, splitK = 1;
+    long yoff = 0, ysize = 0;
+    float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
+    DevEll fwd, adjT, adjRef;
+    bool has_ref = false;
+};
+
+struct ProfRec {
+    const char *name;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct surfh_plan {
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    int Na = 0, Nb = 0, Lc = 0, T = 0, NAP = 0, NBP = 0, KAP = 0, KBP = 0;
+    long PL = 0, PLc = 0;
+    int lo = 0, hi = 0, Lown = 0;
+    int nplanes_m = 0;   // planes of mhat / maps_pad: T, or Lown without LMM
+    float *sotf = nullptr, *tpl = nullptr, *mhat = nullptr, *spec = nullptr, *ycol = nullptr, *cube = nullptr,
+          *partial = nullptr, *maps_pad = nullptr;
+    float *Fi = nullptr, *Gi = nullptr, *Gf = nullptr, *Ff = nullptr;
+    float *io_x = nullptr, *io_y = nullptr;
+    int nchunk = 32;
+    std::vector<Channel> ch;
+    long isize = 0, osize = 0;
+    // CG
+    float *cg_x = nullptr, *cg_r = nullptr, *cg_d = nullptr, *cg_q = nullptr, *cg_b = nullptr, *cg_y = nullptr;
+    double *dscal = nullptr, *dscratch = nullptr;   // [8] device scalars, [1024] partial sums
+    // profiling
+    bool prof = false;
+    std::vector<ProfRec> pending;
+    std::vector<hipEvent_t> pool;
+    std::map<std::string, std::pair<long, double>> acc;
+    std::vector<std::string> acc_names;
+};
+
+namespace {
+
+struct Prof {
+    surfh_plan *p;
+    ProfRec r;
+    bool on;
+    Prof(surfh_plan *pl, const char *name) : p(pl), on(pl->prof) {
+        if (!on) return;
+        r.name = name;
+        for (hipEvent_t *e : {&r.a, &r.b}) {
+            if (!p->pool.empty()) {
+                *e = p->pool.back();
+                p->pool.pop_back();
+            } else {
+                hipEventCreate(e);
+            }
+        }
+        hipEventRecord(r.a, p->stream);
+    }
+    ~Prof() {
+        if (!on) return;
+        hipEventRecord(r.b, p->stream);
+        p->pending.push_back(r);
+    }
+};
+
+void prof_collect(surfh_plan *p) {
+    if (p->pending.empty()) return;
+    hipStreamSynchronize(p->stream);
+    for (auto &r : p->pending) {
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.a, r.b);
+        auto &e = p->acc[r.name];
+        e.first += 1;
+        e.second += ms;
+        p->pool.push_back(r.a);
+        p->pool.push_back(r.b);
+    }
+    p->pending.clear();
+    p->acc_names.clear();
+    for (auto &kv : p->acc) p->acc_names.push_back(kv.first);
+}
+
+template <typename Tp>
+int dev_alloc(Tp **p, size_t n) {
+    HIP_OK(hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(Tp)));
+    return 0;
+}
+
+template <typename Tp>
+int dev_upload(Tp **p, const std::vector<Tp> &h) {
+    if (dev_alloc(p, h.size())) return 1;
+    if (!h.empty()) HIP_OK(hipMemcpy(*p, h.data(), h.size() * sizeof(Tp), hipMemcpyHostToDevice));
+    return 0;
+}
+
+// host-side ELL (rows = outputs)
+struct HostEll {
+    std::vector<std::vector<std::pair<int32_t, float>>> rows;   // (col, val)
+    std::vector<int32_t> dst;
+};
+
+int upload_ell(const HostEll &h, DevEll *d) {
+    const int R = (int)h.rows.size();
+    int W = 0;
+    for (auto &r : h.rows) W = std::max(W, (int)r.size());
+    std::vector<int32_t> cnt(R), col((size_t)R * std::max(W, 1), 0);
+    std::vector<float> val((size_t)R * std::max(W, 1), 0.f);
+    for (int r = 0; r < R; ++r) {
+        cnt[r] = (int32_t)h.rows[r].size();
+        for (int e = 0; e < cnt[r]; ++e) {
+            col[(size_t)e * R + r] = h.rows[r][e].first;
+            val[(size_t)e * R + r] = h.rows[r][e].second;
+        }
+    }
+    if (dev_upload(&d->cnt, cnt) || dev_upload(&d->col, col) || dev_upload(&d->val, val) || dev_upload(&d->dst, h.dst))
+        return 1;
+    d->t.R = R;
+    d->t.W = W;
+    d->t.cnt = d->cnt;
+    d->t.col = d->col;
+    d->t.val = d->val;
+    d->t.dst_off = d->dst;
+    return 0;
+}
+
+void free_ell(DevEll *d) {
+    hipFree(d->cnt);
+    hipFree(d->col);
+    hipFree(d->val);
+    hipFree(d->dst);
+}
+
+// ---------------------------------------------------------------------------------------------
+// table construction for one channel
+// ---------------------------------------------------------------------------------------------
+int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
+    c->ws0 = d.wslice_start;
+    c->ws1 = d.wslice_stop;
+    c->Lin = c->ws1 - c->ws0;
+    c->P = d.n_pointings;
+    c->S = d.n_slit;
+    c->Ldet = d.n_lambda_out;
+    c->aout = d.n_alpha_out;
+    c->srf = d.srf;
+    c->na = d.na;
+    c->nb = d.nb;
+    c->alpha0 = d.alpha0;
+    c->nas = d.n_alpha_slit;
+    c->nbs = d.n_beta_slit;
+    if (c->Lin <= 0 || c->ws0 < 0 || c->ws1 > p->Lc) return fail("channel wslice (%d,%d) outside cube (Lc=%d)", c->ws0, c->ws1, p->Lc);
+    if (c->P < 1 || c->S < 1 || c->Ldet < 1 || c->aout < 1 || c->srf < 1 || c->nbs < 1) return fail("bad channel dims");
+    if ((c->aout - 1) * c->srf >= c->nas) return fail("decimation (alpha_out-1)*srf=%d exceeds the slit alpha window %d", (c->aout - 1) * c->srf, c->nas);
+    if (c->alpha0 < 0 || c->alpha0 + c->nas > c->na) return fail("slit alpha window outside the local grid");
+    if (!d.slit_beta0 || !d.slit_weights || !d.grid_i0 || !d.grid_i1 || !d.grid_y0 || !d.grid_y1 || !d.wpsf)
+        return fail("channel table pointer is NULL");
+    for (int s = 0; s < c->S; ++s)
+        if (d.slit_beta0[s] < 0 || d.slit_beta0[s] + c->nbs > c->nb) return fail("slit %d beta window outside the local grid", s);
+    c->KP = pad64(c->Lin * c->nbs);
+    c->NP = pad64(c->P * c->S * c->aout);
+    c->LdetP = pad64(c->Ldet);
+    c->ysize = (long)c->P * c->S * c->Ldet * c->aout;
+
+    const long nloc = (long)c->na * c->nb;
+    // bounds: the forward gather mirrors bounds_error=True (cython_2D_interpolation.py:472-478);
+    // indices come clamped from find_indices, so only range-check them here.
+    for (long i = 0; i < (long)c->P * nloc; ++i)
+        if (d.grid_i0[i] < 0 || d.grid_i0[i] > p->Na - 2 || d.grid_i1[i] < 0 || d.grid_i1[i] > p->Nb - 2)
+            return fail("bilinear index out of range at local pixel %ld", i);
+
+    // ---- forward ELL: rows (p, a, j-order over (s,b')) ------------------------------------
+    HostEll f;
+    // column -> (slit, b') pairs, in ascending column order
+    std::vector<std::vector<std::pair<int, int>>> colslit(c->nb);
+    for (int s = 0; s < c->S; ++s)
+        for (int b = 0; b < c->nbs; ++b) colslit[d.slit_beta0[s] + b].push_back({s, b});
+    for (int pt = 0; pt < c->P; ++pt)
+        for (int a = 0; a < c->aout; ++a)
+            for (int j = 0; j < c->nb; ++j)
+                for (auto &sb : colslit[j]) {
+                    const int s = sb.first, b = sb.second;
+                    const double ws = d.slit_weights[(long)s * c->nbs + b];
+                    std::vector<std::pair<int32_t, float>> row;
+                    row.reserve(4 * c->srf);
+                    for (int r = 0; r < c->srf; ++r) {
+                        const int i = (c->alpha0 + a * c->srf + r) % c->na;
+                        const long li = (long)pt * nloc + (long)i * c->nb + j;
+                        const int i0 = d.grid_i0[li], i1 = d.grid_i1[li];
+                        const double y0 = d.grid_y0[li], y1 = d.grid_y1[li];
+                        const double w[4] = {(1. - y0) * (1. - y1), (1. - y0) * y1, y0 * (1. - y1), y0 * y1};
+                        const int32_t base = i0 * p->NBP + i1;
+                        const int32_t off[4] = {base, base + 1, base + p->NBP, base + p->NBP + 1};
+                        for (int k = 0; k < 4; ++k) row.push_back({off[k], (float)(w[k] * ws)});
+                    }
+                    f.rows.push_back(std::move(row));
+                    f.dst.push_back((int32_t)((long)b * c->NP + ((long)pt * c->S + s) * c->aout + a));
+                }
+    if (upload_ell(f, &c->fwd)) return 1;
+
+    // ---- exact transpose: rows = touched cube pixels ------------------------------------------
+    {
+        std::map<int32_t, std::map<int32_t, double>> tr;   // pixel -> (src -> weight)
+        for (size_t r = 0; r < f.rows.size(); ++r)
+            for (auto &e : f.rows[r]) tr[e.first][f.dst[r]] += (double)e.second;
+        HostEll t;
+        for (auto &px : tr) {
+            std::vector<std::pair<int32_t, float>> row;
+            for (auto &e : px.second) row.push_back({e.first, (float)e.second});
+            t.rows.push_back(std::move(row));
+            t.dst.push_back(px.first);
+        }
+        if (upload_ell(t, &c->adjT)) return 1;
+    }
+
+    // ---- reference-compatible back-interpolation (gridding_t) ---------------------------------
+    c->has_ref = d.gt_i0 && d.gt_i1 && d.gt_y0 && d.gt_y1 && d.gt_inside;
+    if (c->has_ref) {
+        // local row i' -> list of decimated rows a whose box window contains it
+        std::vector<std::vector<int>> arow(c->na);
+        for (int a = 0; a < c->aout; ++a)
+            for (int r = 0; r < c->srf; ++r) arow[(c->alpha0 + a * c->srf + r) % c->na].push_back(a);
+        HostEll t;
+        const long npix = (long)p->Na * p->Nb;
+        for (int ia = 0; ia < p->Na; ++ia)
+            for (int ib = 0; ib < p->Nb; ++ib) {
+                std::map<int32_t, double> m;
+                for (int pt = 0; pt < c->P; ++pt) {
+                    const long gi = (long)pt * npix + (long)ia * p->Nb + ib;
+                    if (!d.gt_inside[gi]) continue;
+                    const int i0 = d.gt_i0[gi], i1 = d.gt_i1[gi];
+                    if (i0 < 0 || i0 > c->na - 2 || i1 < 0 || i1 > c->nb - 2) return fail("gridding_t index out of range");
+                    const double y0 = d.gt_y0[gi], y1 = d.gt_y1[gi];
+                    const double w[4] = {(1. - y0) * (1. - y1), (1. - y0) * y1, y0 * (1. - y1), y0 * y1};
+                    const int li[4] = {i0, i0, i0 + 1, i0 + 1}, lj[4] = {i1, i1 + 1, i1, i1 + 1};
+                    for (int k = 0; k < 4; ++k)
+                        for (int a : arow[li[k]])
+                            for (auto &sb : colslit[lj[k]]) {
+                                const double ws = d.slit_weights[(long)sb.first * c->nbs + sb.second];
+                                m[(int32_t)((long)sb.second * c->NP + ((long)pt * c->S + sb.first) * c->aout + a)] += w[k] * ws;
+                            }
+                }
+                if (m.empty()) continue;
+                std::vector<std::pair<int32_t, float>> row;
+                for (auto &e : m) row.push_back({e.first, (float)e.second});
+                t.rows.push_back(std::move(row));
+                t.dst.push_back((int32_t)(ia * p->NBP + ib));
+            }
+        if (upload_ell(t, &c->adjRef)) return 1;
+    }
+
+    // ---- spectral PSF as GEMM operands ----------------------------------------------------------
+    {
+        const long K = (long)c->Lin * c->nbs;
+        std::vector<float> W((size_t)c->LdetP * c->KP, 0.f), Wt((size_t)c->KP * c->LdetP, 0.f);
+        for (int l = 0; l < c->Ldet; ++l)
+            for (long k = 0; k < K; ++k) {
+                const float v = (float)d.wpsf[(long)l * K + k];
+                W[(size_t)l * c->KP + k] = v;
+                Wt[(size_t)k * c->LdetP + l] = v;
+            }
+        if (dev_upload(&c->W, W) || dev_upload(&c->Wt, Wt)) return 1;
+    }
+    if (dev_alloc(&c->Xs, (size_t)c->KP * c->NP)) return 1;
+    HIP_OK(hipMemset(c->Xs, 0, (size_t)c->KP * c->NP * sizeof(float)));
+    if (dev_alloc(&c->ymat, (size_t)c->LdetP * c->NP)) return 1;
+    HIP_OK(hipMemset(c->ymat, 0, (size_t)c->LdetP * c->NP * sizeof(float)));
+    return 0;
+}
+
+int pick_split(const Channel &c, int forced) {
+    if (forced > 0) return (c.KP % (16 * forced) == 0) ? forced : 1;
+    const int bm = (c.LdetP % 128 == 0) ? 128 : 64, bn = (c.NP % 128 == 0) ? 128 : 64;
+    const long tiles = (long)(c.LdetP / bm) * (c.NP / bn);
+    int best = 1;
+    for (int s : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
+        if (c.KP % (16 * s)) continue;
+        if (c.KP / s < 256) break;
+        best = s;
+        if (tiles * s >= 768) break;
+    }
+    return best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// DFT matrices (ortho), see the sign/weight conventions in DESIGN.md
+// ---------------------------------------------------------------------------------------------
+void build_dft(const surfh_plan *p, std::vector<float> &Fi, std::vector<float> &Gi, std::vector<float> &Gf,
+               std::vector<float> &Ff) {
+    const int Na = p->Na, Nb = p->Nb, NAP = p->NAP, NBP = p->NBP, KAP = p->KAP, KBP = p->KBP;
+    const int nkb = Nb / 2 + 1;
+    const double sa = 1.0 / std::sqrt((double)Na), sb = 1.0 / std::sqrt((double)Nb);
+    Fi.assign((size_t)2 * NAP * 2 * KAP, 0.f);
+    Ff.assign((size_t)2 * KAP * 2 * NAP, 0.f);
+    Gi.assign((size_t)2 * KBP * NBP, 0.f);
+    Gf.assign((size_t)NBP * 2 * KBP, 0.f);
+    for (int a = 0; a < Na; ++a)
+        for (int k = 0; k < Na; ++k) {
+            const long m = ((long)a * k) % Na;   // exact phase reduction
+            const double th = 2.0 * M_PI * (double)m / (double)Na;
+            const double c = std::cos(th) * sa, s = std::sin(th) * sa;
+            // inverse along alpha: rows (c,alpha), cols (c',k_alpha)
+            Fi[((size_t)0 * NAP + a) * (2 * KAP) + 0 * KAP + k] = (float)c;
+            Fi[((size_t)0 * NAP + a) * (2 * KAP) + 1 * KAP + k] = (float)(-s);
+            Fi[((size_t)1 * NAP + a) * (2 * KAP) + 0 * KAP + k] = (float)s;
+            Fi[((size_t)1 * NAP + a) * (2 * KAP) + 1 * KAP + k] = (float)c;
+            // forward along alpha: rows (c,k_alpha), cols (c',alpha)
+            Ff[((size_t)0 * KAP + k) * (2 * NAP) + 0 * NAP + a] = (float)c;
+            Ff[((size_t)0 * KAP + k) * (2 * NAP) + 1 * NAP + a] = (float)s;
+            Ff[((size_t)1 * KAP + k) * (2 * NAP) + 0 * NAP + a] = (float)(-s);
+            Ff[((size_t)1 * KAP + k) * (2 * NAP) + 1 * NAP + a] = (float)c;
+        }
+    for (int b = 0; b < Nb; ++b)
+        for (int k = 0; k < nkb; ++k) {
+            const long m = ((long)b * k) % Nb;
+            const double th = 2.0 * M_PI * (double)m / (double)Nb;
+            const double c = std::cos(th) * sb, s = std::sin(th) * sb;
+            const double w = (k == 0 || (Nb % 2 == 0 && k == Nb / 2)) ? 1.0 : 2.0;
+            Gi[((size_t)0 * KBP + k) * NBP + b] = (float)(w * c);
+            Gi[((size_t)1 * KBP + k) * NBP + b] = (float)(-w * s);
+            Gf[(size_t)b * (2 * KBP) + 0 * KBP + k] = (float)c;
+            Gf[(size_t)b * (2 * KBP) + 1 * KBP + k] = (float)(-s);
+        }
+}
+
+// ---- the two 2-D transforms as GEMM pairs ----------------------------------------------------
+// real [B][NAP][NBP] -> spec [B][2][KAP][KBP]   (tmp = ycol viewed as [B][NAP][2*KBP])
+int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
+    GemmArgs g;
+    g.A0 = src; g.lda = p->NBP; g.sA = p->PLc;
+    g.B0 = p->Gf; g.ldb = 2 * p->KBP; g.sB = 0;
+    g.C = p->ycol; g.ldc = 2 * p->KBP; g.sC = (long)p->NAP * 2 * p->KBP;
+    g.M = p->NAP; g.N = 2 * p->KBP; g.K = p->NBP; g.batch = B;
+    {
+        Prof pr(p, "gemm_dft_rows_fwd");
+        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+    }
+    GemmArgs h;
+    h.A0 = p->Ff; h.lda = 2 * p->NAP; h.sA = 0;
+    h.B0 = p->ycol; h.B1 = p->ycol + p->KBP; h.ksplitB = p->NAP; h.ldb = 2 * p->KBP; h.sB = (long)p->NAP * 2 * p->KBP;
+    h.C = dst; h.ldc = p->KBP; h.sC = 2 * p->PL;
+    h.M = 2 * p->KAP; h.N = p->KBP; h.K = 2 * p->NAP; h.batch = B;
+    {
+        Prof pr(p, "gemm_dft_cols_fwd");
+        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+    }
+    return 0;
+}
+
+// spec [B][2][KAP][KBP] -> real [B][NAP][NBP]   (tmp = ycol viewed as [B][2][NAP][KBP])
+int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
+    GemmArgs g;
+    g.A0 = p->Fi; g.lda = 2 * p->KAP; g.sA = 0;
+    g.B0 = src; g.ldb = p->KBP; g.sB = 2 * p->PL;
+    g.C = p->ycol; g.ldc = p->KBP; g.sC = (long)2 * p->NAP * p->KBP;
+    g.M = 2 * p->NAP; g.N = p->KBP; g.K = 2 * p->KAP; g.batch = B;
+    {
+        Prof pr(p, "gemm_dft_cols_inv");
+        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+    }
+    GemmArgs h;
+    h.A0 = p->ycol; h.A1 = p->ycol + (long)p->NAP * p->KBP; h.ksplitA = p->KBP; h.lda = p->KBP;
+    h.sA = (long)2 * p->NAP * p->KBP;
+    h.B0 = p->Gi; h.ldb = p->NBP; h.sB = 0;
+    h.C = dst; h.ldc = p->NBP; h.sC = p->PLc;
+    h.M = p->NAP; h.N = p->NBP; h.K = 2 * p->KBP; h.batch = B;
+    {
+        Prof pr(p, "gemm_dft_rows_inv");
+        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pipelines on device buffers
+// ---------------------------------------------------------------------------------------------
+int forward_dev(surfh_plan *p, const float *x, float *y) {
+    hipStream_t s = p->stream;
+    if (p->T > 0) {
+        {
+            Prof pr(p, "pad_planes");
+            LAUNCH_OK(launch_pad_planes(s, x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+        }
+        if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
+    } else {
+        {
+            Prof pr(p, "pad_planes");
+            LAUNCH_OK(launch_pad_planes(s, x + (long)p->lo * p->Na * p->Nb, p->cube, p->Lown, p->Na, p->Nb, p->NAP, p->NBP));
+        }
+        if (rfft2_planes(p, p->cube, p->mhat, p->Lown)) return 1;
+    }
+    {
+        Prof pr(p, "specmix_fwd");
+        LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->Lown, p->PL));
+    }
+    if (irfft2_planes(p, p->spec, p->cube, p->Lown)) return 1;
+    for (auto &c : p->ch) {
+        {
+            Prof pr(p, "spmm_gather_fwd");
+            LAUNCH_OK(launch_spmm_ell(s, c.fwd.t, p->cube + (long)(c.ws0 - p->lo) * p->PLc, p->PLc, c.Xs,
+                                      (long)c.nbs * c.NP, c.Lin, 0));
+        }
+        GemmArgs g;
+        g.A0 = c.W; g.lda = c.KP;
+        g.B0 = c.Xs; g.ldb = c.NP;
+        g.C = c.Cpart; g.ldc = c.NP;
+        g.M = c.LdetP; g.N = c.NP; g.K = c.KP; g.splitK = c.splitK; g.sCsplit = (long)c.LdetP * c.NP;
+        {
+            Prof pr(p, "gemm_wblur_fwd");
+            LAUNCH_OK(launch_gemm_f32(s, g));
+        }
+        {
+            Prof pr(p, "y_from_cpart");
+            LAUNCH_OK(launch_y_from_cpart(s, c.Cpart, (long)c.LdetP * c.NP, c.splitK, y + c.yoff, c.P * c.S, c.Ldet,
+                                          c.aout, c.NP));
+        }
+    }
+    return 0;
+}
+
+int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
+    hipStream_t s = p->stream;
+    {
+        Prof pr(p, "fill_zero");
+        LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->Lown * p->PLc));
+    }
+    for (auto &c : p->ch) {
+        if (ref && !c.has_ref) return fail("adjoint_ref needs the gridding_t tables (gt_*) in the channel descriptor");
+        {
+            Prof pr(p, "ymat_from_y");
+            LAUNCH_OK(launch_ymat_from_y(s, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.NP));
+        }
+        GemmArgs g;
+        g.A0 = c.Wt; g.lda = c.LdetP;
+        g.B0 = c.ymat; g.ldb = c.NP;
+        g.C = c.Xs; g.ldc = c.NP;
+        g.M = c.KP; g.N = c.NP; g.K = c.LdetP;
+        {
+            Prof pr(p, "gemm_wblur_adj");
+            LAUNCH_OK(launch_gemm_f32(s, g));
+        }
+        {
+            Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
+            LAUNCH_OK(launch_spmm_ell(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, (long)c.nbs * c.NP,
+                                      p->cube + (long)(c.ws0 - p->lo) * p->PLc, p->PLc, c.Lin, 1));
+        }
+    }
+    if (rfft2_planes(p, p->cube, p->spec, p->Lown)) return 1;
+    {
+        Prof pr(p, "specmix_adj");
+        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->partial, p->mhat, p->T, p->Lown, p->PL, p->nchunk));
+    }
+    if (p->T > 0) {
+        if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
+        Prof pr(p, "unpad_planes");
+        LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    } else {
+        if (irfft2_planes(p, p->mhat, p->cube, p->Lown)) return 1;
+        const long pl = (long)p->Na * p->Nb;
+        if (p->lo > 0) LAUNCH_OK(launch_fill_zero(s, x, (long)p->lo * pl));
+        if (p->hi < p->Lc) LAUNCH_OK(launch_fill_zero(s, x + (long)p->hi * pl, (long)(p->Lc - p->hi) * pl));
+        Prof pr(p, "unpad_planes");
+        LAUNCH_OK(launch_unpad_planes(s, p->cube, x + (long)p->lo * pl, p->Lown, p->Na, p->Nb, p->NAP, p->NBP));
+    }
+    return 0;
+}
+
+int normal_dev(surfh_plan *p, const float *d, float *q, double mu) {
+    if (forward_dev(p, d, p->cg_y)) return 1;
+    if (adjoint_dev(p, p->cg_y, q, false)) return 1;
+    if (mu != 1.0) {
+        Prof pr(p, "scale");
+        LAUNCH_OK(launch_scale(p->stream, q, p->isize, (float)mu));
+    }
+    return 0;
+}
+
+int ensure_cg(surfh_plan *p) {
+    if (p->cg_x) return 0;
+    for (float **v : {&p->cg_x, &p->cg_r, &p->cg_d, &p->cg_q, &p->cg_b})
+        if (dev_alloc(v, (size_t)p->isize)) return 1;
+    return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *surfh_last_error(void) { return g_err.c_str(); }
+int surfh_version(void) { return 100; }
+
+int surfh_plan_destroy(surfh_plan *p) {
+    if (!p) return 0;
+    hipSetDevice(p->dev);
+    if (p->stream) hipStreamSynchronize(p->stream);
+    for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->partial, p->maps_pad, p->Fi, p->Gi, p->Gf,
+                     p->Ff, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
+        hipFree(v);
+    hipFree(p->dscal);
+    hipFree(p->dscratch);
+    for (auto &c : p->ch) {
+        for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
+        free_ell(&c.fwd);
+        free_ell(&c.adjT);
+        free_ell(&c.adjRef);
+    }
+    for (auto &r : p->pending) {
+        hipEventDestroy(r.a);
+        hipEventDestroy(r.b);
+    }
+    for (auto e : p->pool) hipEventDestroy(e);
+    if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
+    delete p;
+    return 0;
+}
+
+int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
+    if (!cfg || !out) return fail("null argument");
+    *out = nullptr;
+    if (cfg->n_alpha < 2 || cfg->n_beta < 2 || cfg->n_lambda < 1) return fail("bad cube shape");
+    if (cfg->n_channels < 1 || !cfg->channels) return fail("at least one channel is required");
+    if (!cfg->sotf) return fail("sotf is NULL");
+    if (cfg->n_templates > 0 && !cfg->templates) return fail("templates is NULL");
+    int ndev = 0;
+    HIP_OK(hipGetDeviceCount(&ndev));
+    if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not available (%d devices): the HIP path has no CPU fallback", cfg->device, ndev);
+    HIP_OK(hipSetDevice(cfg->device));
+
+    surfh_plan *p = new surfh_plan();
+    p->dev = cfg->device;
+    auto bail = [&](int) {
+        surfh_plan_destroy(p);
+        return 1;
+    };
+    if (cfg->stream) {
+        p->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreate(&p->stream) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+        p->own_stream = true;
+    }
+    p->Na = cfg->n_alpha;
+    p->Nb = cfg->n_beta;
+    p->Lc = cfg->n_lambda;
+    p->T = cfg->n_templates;
+    p->NAP = pad64(p->Na);
+    p->NBP = pad64(p->Nb);
+    p->KAP = p->NAP;
+    p->KBP = pad64(p->Nb / 2 + 1);
+    p->PL = (long)p->KAP * p->KBP;
+    p->PLc = (long)p->NAP * p->NBP;
+    p->lo = p->Lc;
+    p->hi = 0;
+    for (int i = 0; i < cfg->n_channels; ++i) {
+        p->lo = std::min(p->lo, (int)cfg->channels[i].wslice_start);
+        p->hi = std::max(p->hi, (int)cfg->channels[i].wslice_stop);
+    }
+    if (p->lo < 0 || p->hi > p->Lc || p->lo >= p->hi) return bail(fail("channel wslices outside the cube"));
+    p->Lown = p->hi - p->lo;
+    p->nplanes_m = p->T > 0 ? p->T : p->Lown;
+    p->isize = (long)(p->T > 0 ? p->T : p->Lc) * p->Na * p->Nb;
+    p->nchunk = std::max(1, std::min(32, p->Lown / 16));
+
+    // ---- constants ------------------------------------------------------------------------
+    {
+        const int nkb = p->Nb / 2 + 1;
+        if (dev_alloc(&p->sotf, (size_t)p->Lown * 2 * p->PL)) return bail(1);
+        std::vector<float> plane((size_t)2 * p->PL);
+        for (int l = 0; l < p->Lown; ++l) {
+            std::fill(plane.begin(), plane.end(), 0.f);
+            const double *src = cfg->sotf + (size_t)(p->lo + l) * p->Na * nkb * 2;
+            for (int a = 0; a < p->Na; ++a)
+                for (int k = 0; k < nkb; ++k) {
+                    plane[(size_t)a * p->KBP + k] = (float)src[((size_t)a * nkb + k) * 2 + 0];
+                    plane[(size_t)p->PL + (size_t)a * p->KBP + k] = (float)src[((size_t)a * nkb + k) * 2 + 1];
+                }
+            if (hipMemcpy(p->sotf + (size_t)l * 2 * p->PL, plane.data(), plane.size() * sizeof(float),
+                          hipMemcpyHostToDevice) != hipSuccess)
+                return bail(fail("sotf upload failed"));
+        }
+    }
+    if (p->T > 0) {
+        std::vector<float> t((size_t)p->T * p->Lown);
+        for (int k = 0; k < p->T; ++k)
+            for (int l = 0; l < p->Lown; ++l) t[(size_t)k * p->Lown + l] = (float)cfg->templates[(size_t)k * p->Lc + p->lo + l];
+        if (dev_upload(&p->tpl, t)) return bail(1);
+    }
+    {
+        std::vector<float> Fi, Gi, Gf, Ff;
+        build_dft(p, Fi, Gi, Gf, Ff);
+        if (dev_upload(&p->Fi, Fi) || dev_upload(&p->Gi, Gi) || dev_upload(&p->Gf, Gf) || dev_upload(&p->Ff, Ff)) return bail(1);
+    }
+    // ---- work buffers ---------------------------------------------------------------------
+    const size_t nspec = (size_t)p->Lown * 2 * p->PL, ncube = (size_t)p->Lown * p->PLc;
+    const size_t nycol = (size_t)std::max(p->Lown, p->nplanes_m) * 2 * p->NAP * p->KBP;
+    if (dev_alloc(&p->spec, nspec) || dev_alloc(&p->ycol, nycol) || dev_alloc(&p->cube, ncube) ||
+        dev_alloc(&p->mhat, (size_t)p->nplanes_m * 2 * p->PL) ||
+        dev_alloc(&p->maps_pad, (size_t)std::max(p->T, 1) * p->PLc) ||
+        dev_alloc(&p->partial, (size_t)p->nchunk * std::max(p->T, 1) * 2 * p->PL))
+        return bail(1);
+    hipMemset(p->spec, 0, nspec * sizeof(float));
+    hipMemset(p->ycol, 0, nycol * sizeof(float));
+    hipMemset(p->cube, 0, ncube * sizeof(float));
+    hipMemset(p->mhat, 0, (size_t)p->nplanes_m * 2 * p->PL * sizeof(float));
+    hipMemset(p->maps_pad, 0, (size_t)std::max(p->T, 1) * p->PLc * sizeof(float));
+    // ---- channels -------------------------------------------------------------------------
+    p->ch.resize(cfg->n_channels);
+    long yoff = 0;
+    for (int i = 0; i < cfg->n_channels; ++i) {
+        if (build_channel(p, cfg->channels[i], &p->ch[i])) return bail(1);
+        Channel &c = p->ch[i];
+        c.yoff = yoff;
+        yoff += c.ysize;
+        c.splitK = pick_split(c, cfg->split_k_forward);
+        if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
+    }
+    p->osize = yoff;
+    if (dev_alloc(&p->io_x, (size_t)p->isize) || dev_alloc(&p->io_y, (size_t)p->osize) || dev_alloc(&p->cg_y, (size_t)p->osize) ||
+        dev_alloc(&p->dscal, 8) || dev_alloc(&p->dscratch, 1024))
+        return bail(1);
+    if (hipDeviceSynchronize() != hipSuccess) return bail(fail("device error during plan creation: %s", hipGetErrorString(hipGetLastError())));
+    *out = p;
+    return 0;
+}
+
+int64_t surfh_isize(const surfh_plan *p) { return p ? p->isize : -1; }
+int64_t surfh_osize(const surfh_plan *p) { return p ? p->osize : -1; }
+void *surfh_stream(const surfh_plan *p) { return p ? (void *)p->stream : nullptr; }
+
+int surfh_forward_dev(surfh_plan *p, const float *x, float *y) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    return forward_dev(p, x, y);
+}
+int surfh_adjoint_dev(surfh_plan *p, const float *y, float *x) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    return adjoint_dev(p, y, x, false);
+}
+int surfh_adjoint_ref_dev(surfh_plan *p, const float *y, float *x) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    return adjoint_dev(p, y, x, true);
+}
+int surfh_fwadj_dev(surfh_plan *p, const float *x, float *out) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    return normal_dev(p, x, out, 1.0);
+}
+
+static int host_call(surfh_plan *p, const float *in, long nin, float *outp, long nout, int which) {
+    if (!p || !in || !outp) return fail("null argument");
+    HIP_OK(hipSetDevice(p->dev));
+    float *din = (which == 0 || which == 3) ? p->io_x : p->io_y;
+    float *dout = (which == 0) ? p->io_y : p->io_x;
+    if (which == 3) {
+        if (ensure_cg(p)) return 1;
+        dout = p->cg_q;
+    }
+    HIP_OK(hipMemcpyAsync(din, in, nin * sizeof(float), hipMemcpyHostToDevice, p->stream));
+    int rc = 0;
+    if (which == 0) rc = forward_dev(p, din, dout);
+    else if (which == 1) rc = adjoint_dev(p, din, dout, false);
+    else if (which == 2) rc = adjoint_dev(p, din, dout, true);
+    else rc = normal_dev(p, din, dout, 1.0);
+    if (rc) return rc;
+    HIP_OK(hipMemcpyAsync(outp, dout, nout * sizeof(float), hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+
+int surfh_forward(surfh_plan *p, const float *maps, float *y) { return host_call(p, maps, p ? p->isize : 0, y, p ? p->osize : 0, 0); }
+int surfh_adjoint(surfh_plan *p, const float *y, float *maps) { return host_call(p, y, p ? p->osize : 0, maps, p ? p->isize : 0, 1); }
+int surfh_adjoint_ref(surfh_plan *p, const float *y, float *maps) { return host_call(p, y, p ? p->osize : 0, maps, p ? p->isize : 0, 2); }
+int surfh_fwadj(surfh_plan *p, const float *x, float *o) { return host_call(p, x, p ? p->isize : 0, o, p ? p->isize : 0, 3); }
+
+// ---- CG building blocks ---------------------------------------------------------------------
+int surfh_normal_dev(surfh_plan *p, const float *d, float *q, double mu) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    return normal_dev(p, d, q, mu);
+}
+int surfh_prior_add_dev(surfh_plan *p, const float *d, float *q, double mu_reg) {
+    if (!p) return fail("null plan");
+    if (p->T <= 0) return fail("prior is defined on abundance maps (needs templates)");
+    HIP_OK(hipSetDevice(p->dev));
+    Prof pr(p, "prior_add");
+    LAUNCH_OK(launch_prior_add(p->stream, d, q, p->T, p->Na, p->Nb, (float)mu_reg));
+    return 0;
+}
+int surfh_dot_dev(surfh_plan *p, const float *a, const float *b, int64_t n, double *out) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    LAUNCH_OK(launch_dot(p->stream, a, b, n, p->dscratch, p->dscal + 7));
+    HIP_OK(hipMemcpyAsync(out, p->dscal + 7, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+int surfh_cg_step_dev(surfh_plan *p, float *x, float *r, const float *d, const float *q, int64_t n, double rr_in,
+                      double *rr_out) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    HIP_OK(hipMemcpyAsync(p->dscal + 0, &rr_in, sizeof(double), hipMemcpyHostToDevice, p->stream));
+    LAUNCH_OK(launch_dot(p->stream, d, q, n, p->dscratch, p->dscal + 1));
+    LAUNCH_OK(launch_cg_step(p->stream, x, r, d, q, n, p->dscal + 0, p->dscal + 1, p->dscratch, p->dscal + 2));
+    HIP_OK(hipMemcpyAsync(rr_out, p->dscal + 2, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return 0;
+}
+int surfh_cg_dir_dev(surfh_plan *p, float *d, const float *r, int64_t n, double beta) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    const double one = 1.0;
+    HIP_OK(hipMemcpyAsync(p->dscal + 3, &beta, sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipMemcpyAsync(p->dscal + 4, &one, sizeof(double), hipMemcpyHostToDevice, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));   // host scalars are stack variables
+    LAUNCH_OK(launch_cg_dir(p->stream, d, r, n, p->dscal + 3, p->dscal + 4));
+    return 0;
+}
+int surfh_residual_dev(surfh_plan *p, float *r, const float *b, const float *q, int64_t n) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    LAUNCH_OK(launch_residual(p->stream, r, b, q, n));
+    return 0;
+}
+
+// ---- full CG on one GPU (qmm.lcg semantics, see oracle/surfh_oracle.py:lcg) -------------------
+int surfh_cg(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+             int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+    if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
+    if (p->T <= 0) return fail("surfh_cg needs templates (the priors act on abundance maps)");
+    HIP_OK(hipSetDevice(p->dev));
+    if (ensure_cg(p)) return 1;
+    hipStream_t s = p->stream;
+    const long n = p->isize;
+    double *rr = p->dscal + 0, *dq = p->dscal + 1, *rrn = p->dscal + 2;
+    auto Q = [&](const float *v, float *out) -> int {
+        if (normal_dev(p, v, out, mu)) return 1;
+        if (mu_reg != 0.0) {
+            Prof pr(p, "prior_add");
+            LAUNCH_OK(launch_prior_add(s, v, out, p->T, p->Na, p->Nb, (float)mu_reg));
+        }
+        return 0;
+    };
+    // b = mu A^T y
+    HIP_OK(hipMemcpyAsync(p->io_y, y, p->osize * sizeof(float), hipMemcpyHostToDevice, s));
+    if (adjoint_dev(p, p->io_y, p->cg_b, false)) return 1;
+    if (mu != 1.0) LAUNCH_OK(launch_scale(s, p->cg_b, n, (float)mu));
+    if (x0)
+        HIP_OK(hipMemcpyAsync(p->cg_x, x0, n * sizeof(float), hipMemcpyHostToDevice, s));
+    else
+        LAUNCH_OK(launch_fill_zero(s, p->cg_x, n));
+    if (Q(p->cg_x, p->cg_q)) return 1;
+    LAUNCH_OK(launch_residual(s, p->cg_r, p->cg_b, p->cg_q, n));
+    HIP_OK(hipMemcpyAsync(p->cg_d, p->cg_r, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    LAUNCH_OK(launch_dot(s, p->cg_r, p->cg_r, n, p->dscratch, rr));
+    HIP_OK(hipMemcpyAsync(&grad_norm[0], rr, sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    *nit = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        if (Q(p->cg_d, p->cg_q)) return 1;
+        LAUNCH_OK(launch_dot(s, p->cg_d, p->cg_q, n, p->dscratch, dq));
+        if (refresh > 0 && it % refresh == 0) {
+            LAUNCH_OK(launch_cg_xupdate(s, p->cg_x, p->cg_d, n, rr, dq));
+            if (Q(p->cg_x, p->cg_q)) return 1;
+            LAUNCH_OK(launch_residual(s, p->cg_r, p->cg_b, p->cg_q, n));
+            LAUNCH_OK(launch_dot(s, p->cg_r, p->cg_r, n, p->dscratch, rrn));
+        } else {
+            Prof pr(p, "cg_step");
+            LAUNCH_OK(launch_cg_step(s, p->cg_x, p->cg_r, p->cg_d, p->cg_q, n, rr, dq, p->dscratch, rrn));
+        }
+        LAUNCH_OK(launch_cg_dir(s, p->cg_d, p->cg_r, n, rrn, rr));
+        HIP_OK(hipMemcpyAsync(rr, rrn, sizeof(double), hipMemcpyDeviceToDevice, s));
+        HIP_OK(hipMemcpyAsync(&grad_norm[it + 1], rrn, sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        *nit = it + 1;
+        if (std::sqrt(grad_norm[it + 1]) < (double)n * tol) break;
+    }
+    HIP_OK(hipMemcpyAsync(x, p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+}
+
+// ---- instrumentation ------------------------------------------------------------------------
+int surfh_profile_enable(surfh_plan *p, int32_t on) {
+    if (!p) return fail("null plan");
+    p->prof = on != 0;
+    return 0;
+}
+int32_t surfh_profile_count(surfh_plan *p) {
+    if (!p) return -1;
+    hipSetDevice(p->dev);
+    prof_collect(p);
+    return (int32_t)p->acc_names.size();
+}
+int surfh_profile_get(surfh_plan *p, int32_t i, const char **name, int64_t *launches, double *ms) {
+    if (!p || i < 0 || i >= (int32_t)p->acc_names.size()) return fail("bad profile index");
+    auto &e = p->acc[p->acc_names[i]];
+    *name = p->acc_names[i].c_str();
+    *launches = e.first;
+    *ms = e.second;
+    return 0;
+}
+int surfh_profile_reset(surfh_plan *p) {
+    if (!p) return fail("null plan");
+    hipSetDevice(p->dev);
+    prof_collect(p);
+    p->acc.clear();
+    p->acc_names.clear();
+    return 0;
+}
+
+static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t dims[4]) {
+    std::string w(which ? which : "");
+    dims[0] = dims[1] = dims[2] = dims[3] = 1;
+    if (w == "blurred" || w == "gcube") {
+        *ptr = p->cube; dims[0] = p->Lown; dims[1] = p->NAP; dims[2] = p->NBP;
+    } else if (w == "spec") {
+        *ptr = p->spec; dims[0] = p->Lown; dims[1] = 2; dims[2] = p->KAP; dims[3] = p->KBP;
+    } else if (w == "mhat") {
+        *ptr = p->mhat; dims[0] = p->nplanes_m; dims[1] = 2; dims[2] = p->KAP; dims[3] = p->KBP;
+    } else if (w.rfind("xs:", 0) == 0) {
+        const int c = atoi(w.c_str() + 3);
+        if (c < 0 || c >= (int)p->ch.size()) return fail("bad channel index");
+        *ptr = p->ch[c].Xs; dims[0] = p->ch[c].KP; dims[1] = p->ch[c].NP;
+    } else if (w == "info") {
+        *ptr = nullptr; dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->ch.empty() ? 0 : p->ch[0].splitK; dims[3] = p->ch.empty() ? 0 : p->ch[0].adjT.t.W;
+    } else {
+        return fail("unknown debug buffer '%s'", w.c_str());
+    }
+    return 0;
+}
+
+int surfh_debug_dims(surfh_plan *p, const char *which, int64_t dims[4]) {
+    if (!p) return fail("null plan");
+    const float *ptr;
+    return resolve(p, which, &ptr, dims);
+}
+
+int64_t surfh_debug_copy(surfh_plan *p, const char *which, float *out, int64_t cap) {
+    if (!p || !out) return -1;
+    const float *ptr = nullptr;
+    int64_t d[4];
+    if (resolve(p, which, &ptr, d) || !ptr) return -1;
+    const int64_t n = d[0] * d[1] * d[2] * d[3];
+    if (n > cap) {
+        fail("capacity %lld < %lld", (long long)cap, (long long)n);
+        return -1;
+    }
+    hipSetDevice(p->dev);
+    hipStreamSynchronize(p->stream);
+    if (hipMemcpy(out, ptr, n * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
+}
+
+int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split_k, const float *A,
+                        const float *B, float *C) {
+    HIP_OK(hipSetDevice(device));
+    float *dA = nullptr, *dB = nullptr, *dC = nullptr;
+    const int sk = std::max(1, (int)split_k);
+    HIP_OK(hipMalloc((void **)&dA, (size_t)M * K * 4));
+    HIP_OK(hipMalloc((void **)&dB, (size_t)K * N * 4));
+    HIP_OK(hipMalloc((void **)&dC, (size_t)sk * M * N * 4));
+    HIP_OK(hipMemcpy(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice));
+    HIP_OK(hipMemcpy(dB, B, (size_t)K * N * 4, hipMemcpyHostToDevice));
+    GemmArgs g;
+    g.A0 = dA; g.lda = K; g.B0 = dB; g.ldb = N; g.C = dC; g.ldc = N;
+    g.M = M; g.N = N; g.K = K; g.splitK = sk; g.sCsplit = (long)M * N;
+    int rc = launch_gemm_f32(nullptr, g);
+    if (rc == 0) rc = (int)hipDeviceSynchronize();
+    std::vector<float> h((size_t)sk * M * N);
+    if (rc == 0) rc = (int)hipMemcpy(h.data(), dC, h.size() * 4, hipMemcpyDeviceToHost);
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    if (rc) return fail("gemm selftest failed: %s", hipGetErrorString((hipError_t)rc));
+    for (size_t i = 0; i < (size_t)M * N; ++i) {
+        float s = 0.f;
+        for (int k = 0; k < sk; ++k) s += h[(size_t)k * M * N + i];
+        C[i] = s;
+    }
+    return 0;
+}
+
+}  // extern "C"

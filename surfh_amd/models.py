@@ -1,0 +1,245 @@
+"""``spectroSigRLSCT``: the reference's multi-channel multi-observation MRS operator
+(surfh/Models/spectroModel.py:39-185) with the same constructor and methods, evaluated by
+the HIP library through the C ABI (include/surfh_amd.h).
+
+    y = Sigma R L S C T x      (operator chain documented at spectroModel.py:25-38)
+
+``forward`` / ``adjoint`` take and return NumPy arrays (float64 out, for drop-in use with
+a CPU solver); ``*_dev`` variants take device pointers / torch tensors and are
+asynchronous on the plan's stream.  ``adjoint`` is the exact transpose of ``forward``
+(what CG and the dot-test need); ``adjoint_ref`` reproduces the reference's
+interpolating ``gridding_t`` (spectroModelChannel.py:180-199).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from math import ceil
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _lib, instru
+from .geometry import ChannelGeometry
+from .linop import LinOp
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or a raw int)."""
+    if isinstance(t, int):
+        return C.c_void_p(t)
+    return C.c_void_p(t.data_ptr())
+
+
+class spectroSigRLSCT(LinOp):
+    def __init__(self, sotf, templates, alpha_axis, beta_axis, wavelength_axis, instrs: List[instru.IFU],
+                 step_degree: float, pointings: Sequence[instru.CoordList], *, device: int = 0,
+                 channels: Optional[Sequence[int]] = None, with_ref: bool = True, stream: Optional[int] = None,
+                 split_k_forward: int = 0):
+        self.sotf = sotf
+        self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
+        self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
+        self.wavelength_axis = np.asarray(wavelength_axis, dtype=np.float64)
+        self.step_degree = step_degree
+        self.templates = None if templates is None else np.ascontiguousarray(templates, dtype=np.float64)
+        self.lmm = self.templates is not None
+        self.pointings = pointings
+        self.instrs = [i.pix(step_degree) for i in instrs]
+        self.srfs = instru.get_srf([i.det_pix_size for i in instrs], step_degree * 3600)
+        # every channel's geometry is known to every rank; `channels` selects the ones this plan owns
+        self.all_channels = [ChannelGeometry(ins, self.alpha_axis, self.beta_axis, self.wavelength_axis, srf,
+                                             pointings[k], step_degree)
+                             for k, (srf, ins) in enumerate(zip(self.srfs, instrs))]
+        self.owned = list(range(len(instrs))) if channels is None else [int(c) for c in channels]
+        self.channels = [self.all_channels[k] for k in self.owned]
+        self.list_wslice = [c.wslice for c in self.channels]
+        self.instrs_oshape = [c.oshape for c in self.channels]
+        self._idx = np.cumsum([0] + [int(np.prod(s)) for s in self.instrs_oshape])
+        self.full_idx = np.cumsum([0] + [int(np.prod(c.oshape)) for c in self.all_channels])
+        self.imshape = (len(self.alpha_axis), len(self.beta_axis))
+        self.cube_shape = (len(self.wavelength_axis),) + self.imshape
+        lead = self.templates.shape[0] if self.lmm else len(self.wavelength_axis)
+        super().__init__(ishape=(lead,) + self.imshape, oshape=(int(self._idx[-1]),))
+
+        nkb = self.imshape[1] // 2 + 1
+        sotf_c = np.ascontiguousarray(sotf, dtype=np.complex128)
+        if sotf_c.shape != (self.cube_shape[0], self.imshape[0], nkb):
+            raise ValueError(f"sotf shape {sotf_c.shape} != {(self.cube_shape[0], self.imshape[0], nkb)}")
+        if self.lmm and self.templates.shape[1] != self.cube_shape[0]:
+            raise ValueError("templates must be [T, len(wavelength_axis)]")
+
+        L = _lib.load()
+        self._keep = []          # keeps the table arrays alive during plan creation
+        descs = (_lib.ChannelDesc * len(self.channels))()
+        for d, ch in zip(descs, self.channels):
+            t = ch.tables(with_ref=with_ref)   # raises ValueError like the reference if the FoV leaves the cube
+            self._keep.append(t)
+            for k in ("wslice_start", "wslice_stop", "n_pointings", "n_slit", "n_lambda_out", "n_alpha_out", "srf",
+                      "na", "nb", "alpha0", "n_alpha_slit", "n_beta_slit"):
+                setattr(d, k, t[k])
+            d.slit_beta0 = _lib.iptr(t["slit_beta0"])
+            d.slit_weights = _lib.dptr(t["slit_weights"])
+            d.grid_i0, d.grid_i1 = _lib.iptr(t["grid_i0"]), _lib.iptr(t["grid_i1"])
+            d.grid_y0, d.grid_y1 = _lib.dptr(t["grid_y0"]), _lib.dptr(t["grid_y1"])
+            d.wpsf = _lib.dptr(t["wpsf"])
+            if with_ref:
+                d.gt_i0, d.gt_i1 = _lib.iptr(t["gt_i0"]), _lib.iptr(t["gt_i1"])
+                d.gt_y0, d.gt_y1 = _lib.dptr(t["gt_y0"]), _lib.dptr(t["gt_y1"])
+                d.gt_inside = _lib.u8ptr(t["gt_inside"])
+        cfg = _lib.Config()
+        cfg.n_alpha, cfg.n_beta, cfg.n_lambda = self.imshape[0], self.imshape[1], self.cube_shape[0]
+        cfg.n_templates = self.templates.shape[0] if self.lmm else 0
+        cfg.templates = _lib.dptr(self.templates) if self.lmm else None
+        cfg.sotf = sotf_c.view(np.float64).ctypes.data_as(_lib.c_double_p)
+        cfg.n_channels = len(self.channels)
+        cfg.channels = descs
+        cfg.device = device
+        cfg.stream = C.c_void_p(stream) if stream else None
+        cfg.split_k_forward = split_k_forward
+        plan = C.c_void_p()
+        _lib.check(L.surfh_plan_create(C.byref(cfg), C.byref(plan)), ValueError)
+        self._L, self._plan = L, plan
+        self._keep = []
+        assert L.surfh_isize(plan) == self.isize and L.surfh_osize(plan) == self.osize
+        self.device = device
+
+    # ---- life cycle -----------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_plan", None):
+            self._L.surfh_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def alpha_step(self) -> float:
+        return self.alpha_axis[1] - self.alpha_axis[0]
+
+    @property
+    def beta_step(self) -> float:
+        return self.beta_axis[1] - self.beta_axis[0]
+
+    @property
+    def stream(self) -> int:
+        return int(self._L.surfh_stream(self._plan) or 0)
+
+    # ---- host-array API (reference calling convention) --------------------------------------
+    def _host(self, fn, x, nin, shape_out):
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+        if a.size != nin:
+            raise ValueError(f"input has {a.size} elements, expected {nin}")
+        out = np.empty(int(np.prod(shape_out)), dtype=np.float32)
+        _lib.check(fn(self._plan, _lib.fptr(a), _lib.fptr(out)))
+        return out.astype(np.float64).reshape(shape_out)
+
+    def forward(self, maps):
+        return self._host(self._L.surfh_forward, maps, self.isize, self.oshape)
+
+    def adjoint(self, inarray):
+        return self._host(self._L.surfh_adjoint, inarray, self.osize, self.ishape)
+
+    def adjoint_ref(self, inarray):
+        return self._host(self._L.surfh_adjoint_ref, inarray, self.osize, self.ishape)
+
+    def fwadj(self, x):
+        return self._host(self._L.surfh_fwadj, x, self.isize, self.ishape)
+
+    # ---- device-pointer API (asynchronous on self.stream) ----------------------------------
+    def forward_dev(self, maps_t, y_t):
+        _lib.check(self._L.surfh_forward_dev(self._plan, _ptr(maps_t), _ptr(y_t)))
+
+    def adjoint_dev(self, y_t, maps_t):
+        _lib.check(self._L.surfh_adjoint_dev(self._plan, _ptr(y_t), _ptr(maps_t)))
+
+    def adjoint_ref_dev(self, y_t, maps_t):
+        _lib.check(self._L.surfh_adjoint_ref_dev(self._plan, _ptr(y_t), _ptr(maps_t)))
+
+    def normal_dev(self, d_t, q_t, mu: float = 1.0):
+        _lib.check(self._L.surfh_normal_dev(self._plan, _ptr(d_t), _ptr(q_t), float(mu)))
+
+    def prior_add_dev(self, d_t, q_t, mu_reg: float):
+        _lib.check(self._L.surfh_prior_add_dev(self._plan, _ptr(d_t), _ptr(q_t), float(mu_reg)))
+
+    def dot_dev(self, a_t, b_t, n: int) -> float:
+        out = C.c_double()
+        _lib.check(self._L.surfh_dot_dev(self._plan, _ptr(a_t), _ptr(b_t), int(n), C.byref(out)))
+        return out.value
+
+    def cg_step_dev(self, x_t, r_t, d_t, q_t, n: int, rr: float) -> float:
+        out = C.c_double()
+        _lib.check(self._L.surfh_cg_step_dev(self._plan, _ptr(x_t), _ptr(r_t), _ptr(d_t), _ptr(q_t), int(n), float(rr),
+                                             C.byref(out)))
+        return out.value
+
+    def cg_dir_dev(self, d_t, r_t, n: int, beta: float):
+        _lib.check(self._L.surfh_cg_dir_dev(self._plan, _ptr(d_t), _ptr(r_t), int(n), float(beta)))
+
+    def residual_dev(self, r_t, b_t, q_t, n: int):
+        _lib.check(self._L.surfh_residual_dev(self._plan, _ptr(r_t), _ptr(b_t), _ptr(q_t), int(n)))
+
+    # ---- solver on one GPU ------------------------------------------------------------------
+    def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+        y = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
+        if y.size != self.osize:
+            raise ValueError("data size mismatch")
+        x0a = None if x0 is None else np.ascontiguousarray(np.asarray(x0, dtype=np.float32).reshape(-1))
+        x = np.empty(self.isize, dtype=np.float32)
+        gn = np.zeros(max_iter + 1, dtype=np.float64)
+        nit = C.c_int32()
+        _lib.check(self._L.surfh_cg(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
+                                    _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol),
+                                    int(refresh), _lib.fptr(x), _lib.dptr(gn), C.byref(nit)))
+        return x.astype(np.float64).reshape(self.ishape), gn[: nit.value + 1].copy(), nit.value
+
+    # ---- helpers the reference's drivers call -----------------------------------------------
+    def cubeTomaps(self, cube):
+        """lmm_cube2maps (spectroModel.py:187-188): host utility, not on the iteration path."""
+        return np.tensordot(self.templates, np.asarray(cube), axes=(1, 0))
+
+    def mapsToCube(self, maps):
+        """lmm_maps2cube (spectroModel.py:190-198): host utility, not on the iteration path."""
+        return np.tensordot(self.templates.T, np.asarray(maps), axes=(1, 0))
+
+    def real_data_janskySR_to_jansky(self, data):
+        """Jy/sr -> Jy normalisation of slit data (spectroModel.py:225-239)."""
+        out = np.zeros_like(data)
+        for k, ch in enumerate(self.channels):
+            d = np.array(data[self._idx[k]: self._idx[k + 1]]).reshape(self.instrs_oshape[k])
+            for s in range(self.instrs_oshape[k][1]):
+                sl = ch.slicer.get_slit_slices(s)
+                w = ch.slicer.get_slit_weights(s, sl)
+                d[:, s, :, :] = d[:, s, :, :] * np.sum(w[0, 0, :]) * self.srfs[self.owned[k]]
+            out[self._idx[k]: self._idx[k + 1]] = d.ravel()
+        return out
+
+    # ---- instrumentation ---------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _lib.check(self._L.surfh_profile_enable(self._plan, 1 if on else 0))
+
+    def profile_reset(self):
+        _lib.check(self._L.surfh_profile_reset(self._plan))
+
+    def profile(self) -> dict:
+        """{kernel name: (launches, total ms)} measured with HIP events on the plan's stream."""
+        n = self._L.surfh_profile_count(self._plan)
+        out = {}
+        for i in range(n):
+            name, cnt, ms = C.c_char_p(), C.c_int64(), C.c_double()
+            _lib.check(self._L.surfh_profile_get(self._plan, i, C.byref(name), C.byref(cnt), C.byref(ms)))
+            out[name.value.decode()] = (cnt.value, ms.value)
+        return out
+
+    def debug_buffer(self, which: str) -> np.ndarray:
+        dims = (C.c_int64 * 4)()
+        _lib.check(self._L.surfh_debug_dims(self._plan, which.encode(), dims))
+        shape = tuple(int(d) for d in dims)
+        if which == "info":
+            return np.array(shape)
+        out = np.empty(int(np.prod(shape)), dtype=np.float32)
+        n = self._L.surfh_debug_copy(self._plan, which.encode(), _lib.fptr(out), out.size)
+        if n < 0:
+            raise RuntimeError(self._L.surfh_last_error().decode())
+        return out.reshape(shape)

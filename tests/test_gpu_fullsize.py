@@ -1,0 +1,69 @@
+"""Full-size (BASELINE.json config 2: 251x251x1024, band 2A, 4 pointings) checks on the GPU:
+parity of one forward against the float64 oracle, plus size-independent properties
+(dot-test, linearity, zero -> zero)."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import problems
+from helpers import build_model, rel
+from oracle import surfh_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+def config2(Lc=1024):
+    N = 251
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    wav = np.linspace(7.41, 8.87, Lc)
+    spec = problems.band_spec("2a")
+    tpl = orc.synthetic_templates(Lc)
+    sotf = orc.ir2fr(orc.gaussian_psf(wav, problems.STEP), (N, N))
+    pts = orc.dither4(spec.det_pix_size, spec.beta_width / spec.n_slit)
+    maps = np.random.default_rng(19940407).random((4, N, N))
+    return dict(N=N, Lc=Lc, alpha_axis=ax, beta_axis=ax.copy(), wavel=wav, specs=[spec], templates=tpl, sotf=sotf,
+                pointings=[pts], maps=maps, step_deg=problems.STEP_DEG)
+
+
+@pytest.fixture(scope="module")
+def c2():
+    cfg = config2()
+    t = time.time()
+    m = build_model(cfg, with_ref=False)
+    print(f"plan creation {time.time() - t:.1f}s", flush=True)
+    yield cfg, m
+    m.close()
+
+
+def test_config2_shapes(c2):
+    cfg, m = c2
+    assert m.ishape == (4, 251, 251)
+    assert m.instrs_oshape == [(4, 17, 970, 24)] and m.osize == 1583040
+    ch = m.channels[0]
+    assert (ch.wslice.start, ch.wslice.stop) == (0, 1023) and ch.local_im_shape == (171, 203)
+
+
+def test_config2_dottest_and_linearity(c2):
+    cfg, m = c2
+    from surfh_amd import dotgap
+    rng = np.random.default_rng(21)
+    for _ in range(2):
+        l, r = dotgap(m, rng)
+        assert abs(l - r) / abs(r) < 1e-6, (l, r)
+    x1, x2 = rng.standard_normal(m.ishape), rng.standard_normal(m.ishape)
+    assert rel(m.forward(x1 + 3 * x2), m.forward(x1) + 3 * m.forward(x2)) < 1e-5
+    assert np.all(m.forward(np.zeros(m.ishape)) == 0)
+
+
+def test_config2_forward_parity_full_size(c2):
+    cfg, m = c2
+    t = time.time()
+    om = problems.oracle_model(cfg, box="direct")
+    yo = om.forward(cfg["maps"])
+    print(f"oracle forward {time.time() - t:.1f}s", flush=True)
+    y = m.forward(cfg["maps"])
+    e = rel(y, yo)
+    print("config2 forward rel err", e, flush=True)
+    assert e < 1e-5

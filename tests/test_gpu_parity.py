@@ -1,0 +1,220 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the golden vectors
+of the real reference.  Everything here needs a real MI355X (`-m gpu`).
+
+Tolerances: index/integer tables are bit-exact (checked on CPU in test_host_geometry.py);
+the float path is <= 1e-5 relative L2 against the float64 oracle (north_star), the dot-test
+gap is < 1e-6 with fp64-accumulated inner products.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import problems
+from helpers import build_model, rel
+from oracle import surfh_oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+OUT = os.path.join(os.path.dirname(os.path.dirname(__file__)), "gpurun_out")
+TOL = 1e-5
+
+
+def note(name, **kw):
+    os.makedirs(OUT, exist_ok=True)
+    with open(os.path.join(OUT, "parity_log.jsonl"), "a") as f:
+        f.write(json.dumps(dict(test=name, **{k: (float(v) if np.isscalar(v) else v) for k, v in kw.items()})) + "\n")
+
+
+# ----------------------------------------------------------------------------------------------
+def test_gemm_mfma_selftest():
+    from surfh_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(0)
+    for (M, N, K, sk) in [(64, 64, 16, 1), (128, 128, 64, 1), (64, 128, 48, 1), (192, 64, 160, 1),
+                          (128, 192, 256, 2), (256, 128, 384, 3)]:
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = rng.standard_normal((K, N)).astype(np.float32)
+        # asymmetric structure catches transposed fragment maps
+        A += np.arange(M, dtype=np.float32)[:, None] * 0.01
+        B += np.arange(N, dtype=np.float32)[None, :] * 0.02
+        Cg = np.empty((M, N), dtype=np.float32)
+        _lib.check(L.surfh_gemm_selftest(0, M, N, K, sk, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
+        Cr = A.astype(np.float64) @ B.astype(np.float64)
+        e = rel(Cg, Cr)
+        note("gemm", M=M, N=N, K=K, sk=sk, err=e)
+        assert e < 2e-6, (M, N, K, sk, e)
+
+
+@pytest.fixture(scope="module")
+def c1():
+    cfg = problems.config1()
+    om = problems.oracle_model(cfg, box="direct")
+    m = build_model(cfg)
+    yield cfg, om, m
+    m.close()
+
+
+def oracle_xs(om, tab, blurred):
+    """The R-GEMM operand the fused S+box+L+decimation kernel must produce: [(l,b'), (p,s,a)]."""
+    Lin = tab.wslice[1] - tab.wslice[0]
+    nbs = tab.npix_slit_beta_width
+    P, S, _, aout = tab.oshape
+    out = np.zeros((Lin, nbs, P, S, aout))
+    sub = blurred[tab.wslice[0]:tab.wslice[1]]
+    for p in range(P):
+        sc = orc.box_sum_direct(tab, orc.gridding(tab, sub, p))
+        for s in range(S):
+            sl = orc.slicing(tab, sc, s)[:, : aout * tab.srf: tab.srf, :]     # [Lin, aout, nbs]
+            out[:, :, p, s, :] = np.transpose(sl, (0, 2, 1))
+    return out.reshape(Lin * nbs, P * S * aout)
+
+
+def test_stage_blurred_cube(c1):
+    cfg, om, m = c1
+    m.forward(cfg["maps"])
+    N = cfg["N"]
+    b = m.debug_buffer("blurred")[:, :N, :N]
+    lo, hi = int(m.debug_buffer("info")[0]), int(m.debug_buffer("info")[1])
+    ref = om.blur(cfg["maps"])[lo:hi]
+    e = rel(b, ref)
+    note("blurred", err=e)
+    assert e < TOL
+    g = np.load(os.path.join(G, "config1_chain.npz"))
+    sel = [k for k in g["lam_sel"] if lo <= k < hi]
+    assert rel(b[[k - lo for k in sel]], g["blurred_sel"][: len(sel)]) < TOL       # the real reference's planes
+
+
+def test_stage_gemm_operand(c1):
+    cfg, om, m = c1
+    m.forward(cfg["maps"])
+    tab = om.channels[0]
+    ref = oracle_xs(om, tab, om.blur(cfg["maps"]))
+    xs = m.debug_buffer("xs:0")[: ref.shape[0], : ref.shape[1]]
+    e = rel(xs, ref)
+    note("xs", err=e)
+    assert e < TOL
+
+
+def test_forward_vs_oracle_and_reference(c1):
+    cfg, om, m = c1
+    y = m.forward(cfg["maps"])
+    e = rel(y, om.forward(cfg["maps"]))
+    g = np.load(os.path.join(G, "config1_chain.npz"))
+    eg = rel(y, g["y"])
+    note("forward", err=e, err_golden=eg)
+    assert y.shape == (om.osize,) and y.dtype == np.float64
+    assert e < TOL and eg < TOL
+
+
+def test_adjoint_exact_vs_oracle(c1):
+    cfg, om, m = c1
+    u = np.random.default_rng(1).standard_normal(om.osize)
+    a = m.adjoint(u)
+    e = rel(a, om.adjoint(u))
+    note("adjoint", err=e)
+    assert a.shape == om.ishape
+    assert e < TOL
+
+
+def test_adjoint_ref_vs_reference(c1):
+    cfg, om, m = c1
+    g = np.load(os.path.join(G, "config1_chain.npz"))
+    u = np.random.default_rng(int(g["u_seed"])).standard_normal(om.osize)
+    a = m.adjoint_ref(u)
+    e = rel(a, g["adjoint_ref"])
+    note("adjoint_ref", err=e, err_oracle=rel(a, om.adjoint_ref(u)))
+    assert e < TOL
+
+
+def test_dottest(c1):
+    cfg, om, m = c1
+    from surfh_amd import dotgap, dottest
+    gaps = []
+    rng = np.random.default_rng(11)
+    for _ in range(5):
+        l, r = dotgap(m, rng)
+        gaps.append(abs(l - r) / abs(r))
+    note("dottest", gaps=[float(x) for x in gaps])
+    assert max(gaps) < 1e-6
+    assert dottest(m, num=2, rng=rng)
+
+
+def test_fwadj_and_linearity(c1):
+    cfg, om, m = c1
+    rng = np.random.default_rng(3)
+    x1, x2 = rng.standard_normal(om.ishape), rng.standard_normal(om.ishape)
+    assert rel(m.fwadj(x1), m.adjoint(m.forward(x1))) < 1e-6
+    assert rel(m.forward(2.0 * x1 - 0.5 * x2), 2.0 * m.forward(x1) - 0.5 * m.forward(x2)) < 1e-5
+
+
+def test_two_channel_overlap():
+    cfg = problems.two_channel_small()
+    om = problems.oracle_model(cfg, box="direct")
+    m = build_model(cfg)
+    g = np.load(os.path.join(G, "two_channel.npz"))
+    assert np.array_equal(m._idx, g["idx"])
+    y = m.forward(cfg["maps"])
+    u = np.random.default_rng(int(g["u_seed"])).standard_normal(om.osize)
+    e = dict(fwd=rel(y, g["y"]), adj=rel(m.adjoint(u), om.adjoint(u)), adj_ref=rel(m.adjoint_ref(u), g["adjoint_ref"]))
+    note("two_channel", **e)
+    assert max(e.values()) < TOL
+    from surfh_amd import dotgap
+    l, r = dotgap(m, np.random.default_rng(4))
+    assert abs(l - r) / abs(r) < 1e-6
+    m.close()
+
+
+def test_no_lmm_mode():
+    """templates=None switches the LMM off (spectroModel.py:60-63,92-95): input is the cube."""
+    cfg = dict(problems.two_channel_small())
+    cfg["templates"] = None
+    om = problems.oracle_model(cfg, box="direct")
+    m = build_model(cfg)
+    cube = np.random.default_rng(5).random(om.ishape)
+    u = np.random.default_rng(6).standard_normal(om.osize)
+    e = dict(fwd=rel(m.forward(cube), om.forward(cube)), adj=rel(m.adjoint(u), om.adjoint(u)))
+    note("no_lmm", **e)
+    assert max(e.values()) < TOL
+    m.close()
+
+
+def test_cg_matches_oracle_lcg(c1):
+    cfg, om, m = c1
+    y = om.forward(cfg["maps"])
+    y = y + np.random.default_rng(1).standard_normal(y.size) * 1e-2 * np.sqrt(np.mean(y ** 2))
+    mu, mur, nit = 1.0, 5e3, 12
+    ref = orc.lcg(om, y, mu, mur, np.zeros(om.ishape), tol=1e-12, max_iter=nit)
+    x, gn, n = m.cg(y, mu=mu, mu_reg=mur, x0=None, max_iter=nit, tol=1e-12)
+    gr = np.array(ref["grad_norm"])
+    e = rel(x, ref["x"])
+    ge = float(np.max(np.abs(gn - gr) / gr))
+    note("cg", err_x=e, err_gradnorm=ge, nit=n, gn_first=float(gn[0]), gn_last=float(gn[-1]))
+    assert n == nit and len(gn) == nit + 1
+    assert e < 1e-3 and ge < 1e-2
+    c = [orc.crit_val(om, y, m.cg(y, mu=mu, mu_reg=mur, max_iter=k)[0], mu, mur) for k in (1, 4, 8)]
+    assert c[0] > c[1] > c[2]
+
+
+def test_device_pointer_api_and_profile(c1):
+    import torch
+    cfg, om, m = c1
+    dev = torch.device("cuda:0")
+    x = torch.tensor(cfg["maps"], dtype=torch.float32, device=dev).contiguous()
+    y = torch.empty(om.osize, dtype=torch.float32, device=dev)
+    q = torch.empty_like(x)
+    torch.cuda.synchronize()
+    m.profile_reset()
+    m.profile_enable(True)
+    m.forward_dev(x, y)
+    m.normal_dev(x, q, 1.0)
+    prof = m.profile()
+    m.profile_enable(False)
+    torch.cuda.synchronize()
+    assert rel(y.cpu().numpy(), om.forward(cfg["maps"])) < TOL
+    assert rel(q.cpu().numpy(), om.adjoint(om.forward(cfg["maps"]))) < TOL
+    assert prof["gemm_wblur_fwd"][0] == 2 and prof["gemm_wblur_adj"][0] == 1
+    assert all(ms >= 0 for _, ms in prof.values())
+    n = om.isize
+    assert abs(m.dot_dev(x, x, n) - float(np.sum(cfg["maps"].astype(np.float32).astype(np.float64) ** 2))) < 1e-6 * n
