@@ -1,0 +1,197 @@
+#!/usr/bin/env python
+"""Benchmark of the surfh hot path on MI355X: CG iterations / second.
+
+    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+
+A "step" is one iteration of the regularised least-squares linear CG (qmm.lcg loop body,
+surfh/Simulation/fusion_CT.py:194-225): one forward + one exact-transpose adjoint of the MRS
+operator, the two first-difference priors and the vector updates.  The workload is the
+configuration BASELINE.json's metric is quoted on: the 4-channel (1C, 2A, 2B, 2C) 251x251x4000
+synthetic cube with a 4-point dither.  It fits one GPU, so N=1 runs all
+four bands on one MI355X; for N>1 the same problem is sharded by (band, pointings) units and the
+only exchange is one RCCL all-reduce of the [T,251,251] normal-equation product per iteration
+(total work fixed -> "strong" scaling).  `--config 2` runs BASELINE.json configs[1]
+(single band 2A, 251x251x1024) instead.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for how `roofline` and `cpu_baseline`
+are formed.  Inputs are resident in HBM before the timed region starts.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA peak
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(cfg_name: str, budget_s: float):
+    """The oracle (float64 NumPy/SciPy port of the reference chain) timed on the host cores on a
+    bounded sample of the same workload: every `stride`-th cube plane, full detector axes,
+    all bands and pointings; every stage costs ~1/stride of the full problem, so the
+    full-size rate is sample_rate / stride."""
+    from oracle import surfh_oracle as orc
+    from surfh_amd import synth
+    stride = 16 if cfg_name == "2" else 32
+    prob = (synth.config2 if cfg_name == "2" else synth.config3)(lam_stride=stride)
+    specs = [orc.ChannelSpec(i.fov.alpha_width, i.fov.beta_width, (0.0, 0.0), i.fov.angle, i.det_pix_size, i.n_slit,
+                             i.w_blur.grating_resolution, i.wavel_axis, i.name) for i in prob["ifus"]]
+    pts = [[(c.alpha, c.beta) for c in pl] for pl in prob["pointings"]]
+    t0 = time.time()
+    om = orc.OracleModel(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"], prob["wavel"], specs,
+                         prob["step_deg"], pts, box="direct")
+    log(f"[cpu_baseline] oracle setup {time.time() - t0:.1f}s, Lc_sample={len(prob['wavel'])}")
+    d = np.random.default_rng(0).standard_normal(om.ishape)
+    t_all = time.time()
+    orc.normal_apply(om, d, 1.0, 5e3)             # warm-up (counts against the budget)
+    times = []
+    while len(times) < 3 and (not times or (time.time() - t_all) + times[-1] < budget_s):
+        t = time.time()
+        orc.normal_apply(om, d, 1.0, 5e3)
+        times.append(time.time() - t)
+    t_it = float(np.median(times))
+    return {"value": 1.0 / (t_it * stride), "unit": "it/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": f"oracle normal-operator application (1 fwd + 1 exact adj + priors) on every {stride}th cube plane "
+                      f"({len(prob['wavel'])} of {len(prob['wavel']) * stride} planes), all bands/pointings, full detector axes; "
+                      f"{len(times)} timed reps, median {t_it:.2f}s; full-size rate = sample rate / {stride}",
+            "seconds_per_sample_iteration": t_it}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="3", choices=["2", "3"])
+    ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
+    ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+
+    from surfh_amd import synth
+    from surfh_amd.fusion import DistributedFusion
+    t0 = time.time()
+    prob = synth.config2() if args.config == "2" else synth.config3()
+    log(f"[rank {rank}] problem built in {time.time() - t0:.1f}s")
+    t0 = time.time()
+    fus = DistributedFusion(prob, rank=rank, world=world, device=local)
+    m = fus.model
+    log(f"[rank {rank}] plan built in {time.time() - t0:.1f}s; units {fus.units}; osize {m.osize}")
+    y = fus.make_data(prob["maps"])
+    mu, mu_reg = 1.0, 5e3
+    fus.start(y, mu, mu_reg, x0=None)
+    for _ in range(args.warmup):
+        fus.step()
+
+    def fence():
+        fus.tstream.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    if not args.no_profile:
+        m.profile_reset()
+        m.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fus.step()
+    fence()
+    el = time.perf_counter() - t0
+    prof = {}
+    if not args.no_profile:
+        prof = m.profile()
+        m.profile_enable(False)
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+
+    if rank == 0:
+        N = len(prob["alpha_axis"])
+        Nf = N * (N // 2 + 1)
+        info = m.debug_buffer("info")
+        Lown = int(info[1] - info[0])
+        groups = {}
+        for name, (cnt, ms) in prof.items():
+            g = "gemm_dft" if name.startswith("gemm_dft_") and not name.endswith("_maps") else \
+                "gemm_wblur" if name.startswith("gemm_wblur") else name
+            a = groups.setdefault(g, [0, 0.0])
+            a[0] += cnt
+            a[1] += ms
+        roof = None
+        stage_ms = {k: round(v[1] / args.steps, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][1])}
+        if groups:
+            dom = max(groups, key=lambda k: groups[k][1])
+            cnt, ms = groups[dom]
+            if dom == "gemm_wblur":
+                flops = sum(2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
+                            for c in m.channels)   # per launch, averaged over the fwd/adj launches of all channels
+                per_launch = flops / max(1, len(m.channels)) * 1.0
+                ach = per_launch / (ms / cnt * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "gemm_f32_kernel (R / R^T)",
+                        "launches": cnt, "avg_ms": ms / cnt}
+            else:
+                # FFT-conv stage: one 2-D transform pass over the owned planes algorithmically moves
+                # Lown*(Nf*8 + N^2*4) bytes; each pass is two 1-D launches of this kernel.
+                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4)
+                ach = bytes_launch / (ms / cnt * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": f"{dom} (gemm_f32_kernel as 1-D DFT pass over {Lown} planes)" if dom == "gemm_dft" else dom,
+                        "launches": cnt, "avg_ms": ms / cnt}
+        out = {
+            "metric": "CG-iterations/sec (forward+adjoint) on 251x251x4000 cube" if args.config == "3"
+                      else "CG-iterations/sec (forward+adjoint) on 251x251x1024 cube",
+            "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("config3: 4 MRS bands 1C,2A,2B,2C, 251x251x4000 cube, 4-point dither, T=4, mu_reg=5e3"
+                                    if args.config == "3" else
+                                    "config2: band 2A, 251x251x1024 cube, 4-point dither, T=4, mu_reg=5e3"),
+                       "parallelism": f"{world} rank(s), (band,pointings) units {fus.assignment}",
+                       "osize_rank0": int(m.osize), "grad_norm_first_last": [fus.grad_norm[0], fus.grad_norm[-1]]},
+            "roofline": roof, "stage_ms_per_step": stage_ms,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
+            except Exception as e:   # the baseline leg must never hide the GPU number
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

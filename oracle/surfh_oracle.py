@@ -427,7 +427,10 @@ def wblur_subsampling(sliced, wpsf):
 
 def wblur_t(arr, wpsf):
     """jax_utils.wblur_t (:83-91): x[l,a,b] = sum_l' y[l',a,b] W[l',l,b]."""
-    return np.einsum("kab,klb->lab", arr, wpsf, optimize=True)
+    out = np.empty((wpsf.shape[1], arr.shape[1], arr.shape[2]), dtype=np.result_type(arr, wpsf))
+    for b in range(arr.shape[2]):                      # one BLAS product per beta column
+        out[:, :, b] = wpsf[:, :, b].T @ arr[:, :, b]
+    return out
 
 
 def channel_forward(tab: ChannelTables, blurred_cube, box="fft", stages=None):

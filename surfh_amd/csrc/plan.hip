@@ -387,14 +387,14 @@ void build_dft(const surfh_plan *p, std::vector<float> &Fi, std::vector<float> &
 
 // ---- the two 2-D transforms as GEMM pairs ----------------------------------------------------
 // real [B][NAP][NBP] -> spec [B][2][KAP][KBP]   (tmp = ycol viewed as [B][NAP][2*KBP])
-int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
+int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B, bool maps = false) {
     GemmArgs g;
     g.A0 = src; g.lda = p->NBP; g.sA = p->PLc;
     g.B0 = p->Gf; g.ldb = 2 * p->KBP; g.sB = 0;
     g.C = p->ycol; g.ldc = 2 * p->KBP; g.sC = (long)p->NAP * 2 * p->KBP;
     g.M = p->NAP; g.N = 2 * p->KBP; g.K = p->NBP; g.batch = B;
     {
-        Prof pr(p, "gemm_dft_rows_fwd");
+        Prof pr(p, maps ? "gemm_dft_rows_fwd_maps" : "gemm_dft_rows_fwd");
         LAUNCH_OK(launch_gemm_f32(p->stream, g));
     }
     GemmArgs h;
@@ -403,21 +403,21 @@ int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     h.C = dst; h.ldc = p->KBP; h.sC = 2 * p->PL;
     h.M = 2 * p->KAP; h.N = p->KBP; h.K = 2 * p->NAP; h.batch = B;
     {
-        Prof pr(p, "gemm_dft_cols_fwd");
+        Prof pr(p, maps ? "gemm_dft_cols_fwd_maps" : "gemm_dft_cols_fwd");
         LAUNCH_OK(launch_gemm_f32(p->stream, h));
     }
     return 0;
 }
 
 // spec [B][2][KAP][KBP] -> real [B][NAP][NBP]   (tmp = ycol viewed as [B][2][NAP][KBP])
-int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
+int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B, bool maps = false) {
     GemmArgs g;
     g.A0 = p->Fi; g.lda = 2 * p->KAP; g.sA = 0;
     g.B0 = src; g.ldb = p->KBP; g.sB = 2 * p->PL;
     g.C = p->ycol; g.ldc = p->KBP; g.sC = (long)2 * p->NAP * p->KBP;
     g.M = 2 * p->NAP; g.N = p->KBP; g.K = 2 * p->KAP; g.batch = B;
     {
-        Prof pr(p, "gemm_dft_cols_inv");
+        Prof pr(p, maps ? "gemm_dft_cols_inv_maps" : "gemm_dft_cols_inv");
         LAUNCH_OK(launch_gemm_f32(p->stream, g));
     }
     GemmArgs h;
@@ -427,7 +427,7 @@ int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     h.C = dst; h.ldc = p->NBP; h.sC = p->PLc;
     h.M = p->NAP; h.N = p->NBP; h.K = 2 * p->KBP; h.batch = B;
     {
-        Prof pr(p, "gemm_dft_rows_inv");
+        Prof pr(p, maps ? "gemm_dft_rows_inv_maps" : "gemm_dft_rows_inv");
         LAUNCH_OK(launch_gemm_f32(p->stream, h));
     }
     return 0;
@@ -443,7 +443,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             Prof pr(p, "pad_planes");
             LAUNCH_OK(launch_pad_planes(s, x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
         }
-        if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
+        if (rfft2_planes(p, p->maps_pad, p->mhat, p->T, true)) return 1;
     } else {
         {
             Prof pr(p, "pad_planes");
@@ -513,7 +513,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
         LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->partial, p->mhat, p->T, p->Lown, p->PL, p->nchunk));
     }
     if (p->T > 0) {
-        if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
+        if (irfft2_planes(p, p->mhat, p->maps_pad, p->T, true)) return 1;
         Prof pr(p, "unpad_planes");
         LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     } else {

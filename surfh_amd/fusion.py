@@ -1,0 +1,210 @@
+"""Regularised least-squares fusion by linear CG on top of ``spectroSigRLSCT``.
+
+* ``QuadCriterion_MRS`` mirrors the reference's criterion class
+  (surfh/Simulation/fusion_CT.py:66-265): same constructor, ``run_method('lcg', ...)``,
+  ``get_crit_val``; the solver it drives is the library's device-resident CG
+  (``qmm.lcg`` restated, see include/surfh_amd.h:surfh_cg).
+* ``DistributedFusion`` is the multi-GPU form: one process per GPU, each rank owns a set of
+  (band, pointings) units, x/r/d are replicated, and the only exchange per iteration is one
+  RCCL all-reduce (sum) of the partial normal-equation product mu * A_r^T A_r d  ([T, Na, Nb] fp32)
+  through ``torch.distributed``.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import instru
+from .models import spectroSigRLSCT
+
+
+@dataclass
+class OptimizeResult:
+    x: np.ndarray
+    grad_norm: List[float] = field(default_factory=list)
+    nit: int = 0
+    success: bool = False
+    time: float = 0.0
+
+
+class QuadCriterion_MRS:
+    def __init__(self, mu_spectro, y_spectro, model_spectro, mu_reg, printing=False, gradient="separated"):
+        assert isinstance(mu_reg, (float, int, list, np.ndarray))
+        if gradient != "separated":
+            raise NotImplementedError("only the separated first-difference priors (NpDiff_r / NpDiff_c) are built")
+        self.mu_spectro, self.y_spectro, self.model_spectro, self.mu_reg = mu_spectro, y_spectro, model_spectro, mu_reg
+        self.n_spec = model_spectro.ishape[0]
+        self.shape_of_output = tuple(model_spectro.ishape)
+        self.printing, self.gradient, self.it = printing, gradient, 1
+        self.L_crit_val = []
+
+    def run_method(self, method="lcg", maximum_iterations=10, tolerance=1e-12, calc_crit=False, perf_crit=None,
+                   value_init=0.5):
+        assert isinstance(self.mu_reg, (int, float))       # fusion_CT.py:119
+        if method != "lcg":
+            raise NotImplementedError("only method='lcg' is built (mmmg is out of the hot-path scope)")
+        if isinstance(value_init, (int, float)):
+            init = np.ones(self.shape_of_output) * value_init
+        else:
+            assert value_init.shape == self.shape_of_output
+            init = value_init
+        import time
+        t0 = time.time()
+        x, gn, nit = self.model_spectro.cg(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
+                                           max_iter=maximum_iterations, tol=tolerance)
+        res = OptimizeResult(x=x.ravel(), grad_norm=list(gn), nit=nit,
+                             success=bool(np.sqrt(gn[-1]) < x.size * tolerance), time=time.time() - t0)
+        if calc_crit:
+            self.L_crit_val.append(self.get_crit_val(x))
+        if self.printing:
+            print(f"Total time needed for {method} :", round(res.time, 3))
+        return res
+
+    def get_crit_val(self, x_hat):
+        """(mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2)) / 2   (fusion_CT.py:242-265)."""
+        x_hat = np.asarray(x_hat).reshape(self.shape_of_output)
+        data = self.mu_spectro * np.sum((self.y_spectro - self.model_spectro.forward(x_hat)) ** 2)
+        dr = np.roll(x_hat, 1, axis=1) - x_hat
+        dc = np.roll(x_hat, 1, axis=2) - x_hat
+        return (data + self.mu_reg * np.sum(dr ** 2 + dc ** 2)) / 2
+
+
+# ------------------------------------------------------------------------------------------------
+# multi-GPU
+# ------------------------------------------------------------------------------------------------
+def band_cost(n_pix: int, geo) -> float:
+    """Relative cost of one band per CG iteration: dense-contraction flops (R, R^T and the two
+    2-D transforms of its lambda window) -- the quantity the per-rank time follows."""
+    P, S, Ldet, aout = geo.oshape
+    Lin = geo.wslice.stop - geo.wslice.start
+    nbs = geo.slicer.npix_slit_beta_width
+    r = 4.0 * P * S * Ldet * Lin * nbs * aout
+    fft = 2.0 * Lin * 12.0 * n_pix ** 3
+    return r + fft
+
+
+def partition_units(costs: Sequence[float], n_pointings: Sequence[int], world: int) -> List[List[Tuple[int, List[int]]]]:
+    """Assign (band, pointing subset) units to ranks.  world <= bands: whole bands, longest-processing-time
+    greedy; world > bands: every band gets >= 1 ranks (the costliest bands get the extra ones) and its
+    pointings are split contiguously among them (pointings are additive, spectroModelChannel.py:236-262)."""
+    nb = len(costs)
+    out: List[List[Tuple[int, List[int]]]] = [[] for _ in range(world)]
+    if world <= nb:
+        load = [0.0] * world
+        for k in sorted(range(nb), key=lambda i: -costs[i]):
+            r = int(np.argmin(load))
+            out[r].append((k, list(range(n_pointings[k]))))
+            load[r] += costs[k]
+        for r in range(world):
+            out[r].sort()
+        return out
+    share = [1] * nb
+    for _ in range(world - nb):
+        k = int(np.argmax([costs[i] / share[i] if share[i] < n_pointings[i] else -1.0 for i in range(nb)]))
+        share[k] += 1
+    r = 0
+    for k in range(nb):
+        groups = np.array_split(np.arange(n_pointings[k]), share[k])
+        for g in groups:
+            out[r].append((k, [int(i) for i in g]))
+            r += 1
+    return out
+
+
+class DistributedFusion:
+    """One rank of the channel-sharded CG.  ``prob`` is a dict as produced by ``surfh_amd.synth.problem``."""
+
+    def __init__(self, prob: dict, rank: int = 0, world: int = 1, device: int = 0, with_ref: bool = False):
+        import torch
+        self.torch = torch
+        self.rank, self.world, self.device = rank, world, device
+        ifus, pts = prob["ifus"], prob["pointings"]
+        n_pix = len(prob["alpha_axis"])
+        # geometry of every band (cheap) -> costs -> unit assignment, identical on every rank
+        from .geometry import ChannelGeometry
+        srfs = instru.get_srf([i.det_pix_size for i in ifus], prob["step_deg"] * 3600)
+        geos = [ChannelGeometry(i, prob["alpha_axis"], prob["beta_axis"], prob["wavel"], s, p, prob["step_deg"])
+                for i, s, p in zip(ifus, srfs, pts)]
+        self.costs = [band_cost(n_pix, g) for g in geos]
+        self.assignment = partition_units(self.costs, [len(p) for p in pts], world)
+        self.units = self.assignment[rank]
+        torch.cuda.set_device(device)
+        self.tstream = torch.cuda.Stream(device=device)
+        my_ifus = [ifus[k] for k, _ in self.units]
+        my_pts = [instru.CoordList([pts[k][i] for i in sel]) for k, sel in self.units]
+        self.model = spectroSigRLSCT(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"],
+                                     prob["wavel"], my_ifus, prob["step_deg"], my_pts, device=device,
+                                     with_ref=with_ref, stream=self.tstream.cuda_stream)
+        self.n = self.model.isize
+
+    def _allreduce(self, t):
+        if self.world > 1:
+            self.torch.distributed.all_reduce(t)
+
+    def make_data(self, maps, noise_rel=1e-2, seed=1):
+        """y_r = A_r maps + N(0, sigma^2), sigma = noise_rel * rms(y_r)."""
+        torch = self.torch
+        with torch.cuda.stream(self.tstream):
+            x = torch.as_tensor(np.ascontiguousarray(maps, dtype=np.float32), device=f"cuda:{self.device}")
+            y = torch.empty(self.model.osize, dtype=torch.float32, device=x.device)
+            self.model.forward_dev(x, y)
+            g = torch.Generator(device=x.device).manual_seed(seed + self.rank)
+            y += torch.randn(y.shape, generator=g, device=x.device, dtype=torch.float32) * (noise_rel * y.square().mean().sqrt())
+        self.tstream.synchronize()
+        return y
+
+    def normal(self, d, q, mu, mu_reg):
+        """q = mu A^T A d (summed over ranks) + mu_reg (Dr^T Dr + Dc^T Dc) d."""
+        self.model.normal_dev(d, q, mu)
+        self._allreduce(q)
+        if mu_reg:
+            self.model.prior_add_dev(d, q, mu_reg)
+
+    def start(self, y, mu=1.0, mu_reg=0.0, x0=None):
+        torch, m = self.torch, self.model
+        dev = f"cuda:{self.device}"
+        with torch.cuda.stream(self.tstream):
+            shape = m.ishape
+            self.x = torch.zeros(shape, dtype=torch.float32, device=dev) if x0 is None else \
+                torch.as_tensor(np.ascontiguousarray(x0, dtype=np.float32), device=dev).clone()
+            self.b = torch.empty_like(self.x)
+            self.q = torch.empty_like(self.x)
+            m.adjoint_dev(y, self.b)
+            if mu != 1.0:
+                self.b *= mu
+            self._allreduce(self.b)
+            self.normal(self.x, self.q, mu, mu_reg)
+            self.r = self.b - self.q
+            self.d = self.r.clone()
+            self.rr = m.dot_dev(self.r, self.r, self.n)
+        self.mu, self.mu_reg = mu, mu_reg
+        self.grad_norm = [self.rr]
+        self.it = 0
+
+    def step(self, refresh=50):
+        """One CG iteration (qmm.lcg loop body; oracle/surfh_oracle.py:lcg documents the recurrences)."""
+        torch, m = self.torch, self.model
+        with torch.cuda.stream(self.tstream):
+            self.normal(self.d, self.q, self.mu, self.mu_reg)
+            rr_new = m.cg_step_dev(self.x, self.r, self.d, self.q, self.n, self.rr)
+            if refresh and self.it % refresh == 0:
+                self.normal(self.x, self.q, self.mu, self.mu_reg)
+                m.residual_dev(self.r, self.b, self.q, self.n)
+                rr_new = m.dot_dev(self.r, self.r, self.n)
+            m.cg_dir_dev(self.d, self.r, self.n, rr_new / self.rr)
+        self.rr = rr_new
+        self.grad_norm.append(rr_new)
+        self.it += 1
+        return rr_new
+
+    def lcg(self, y, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+        self.start(y, mu, mu_reg, x0)
+        for _ in range(max_iter):
+            rr = self.step(refresh)
+            if np.sqrt(rr) < self.n * tol:
+                break
+        self.tstream.synchronize()
+        return OptimizeResult(x=self.x.cpu().numpy().astype(np.float64), grad_norm=list(self.grad_norm), nit=self.it,
+                              success=bool(np.sqrt(self.rr) < self.n * tol))

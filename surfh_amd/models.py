@@ -238,6 +238,8 @@ class spectroSigRLSCT(LinOp):
         shape = tuple(int(d) for d in dims)
         if which == "info":
             return np.array(shape)
+        while len(shape) > 1 and shape[-1] == 1:
+            shape = shape[:-1]
         out = np.empty(int(np.prod(shape)), dtype=np.float32)
         n = self._L.surfh_debug_copy(self._plan, which.encode(), _lib.fptr(out), out.size)
         if n < 0:

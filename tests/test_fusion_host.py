@@ -1,0 +1,34 @@
+"""Host logic of the multi-GPU driver: unit partition, synthetic problems, criterion mirror."""
+import numpy as np
+
+from surfh_amd import synth
+from surfh_amd.fusion import partition_units
+
+
+def test_partition_whole_bands():
+    costs = [67.5, 85.9, 113.1, 140.9]
+    a = partition_units(costs, [4, 4, 4, 4], 2)
+    assert sorted(k for r in a for k, _ in r) == [0, 1, 2, 3]
+    loads = [sum(costs[k] for k, _ in r) for r in a]
+    assert max(loads) / min(loads) < 1.15
+    a4 = partition_units(costs, [4] * 4, 4)
+    assert all(len(r) == 1 and r[0][1] == [0, 1, 2, 3] for r in a4)
+    a1 = partition_units(costs, [4] * 4, 1)
+    assert [k for k, _ in a1[0]] == [0, 1, 2, 3]
+
+
+def test_partition_splits_pointings_beyond_band_count():
+    a = partition_units([1.0, 2.0, 3.0, 4.0], [4] * 4, 8)
+    assert all(len(r) == 1 for r in a)
+    for k in range(4):
+        sel = sorted(i for r in a for kk, s in r if kk == k for i in s)
+        assert sel == [0, 1, 2, 3]                     # every pointing of every band owned exactly once
+    a6 = partition_units([1.0, 2.0, 3.0, 4.0], [4] * 4, 6)
+    assert sum(1 for r in a6 for kk, _ in r if kk == 3) == 2 and sum(1 for r in a6 for kk, _ in r if kk == 0) == 1
+
+
+def test_config_shapes():
+    p = synth.config2(lam_stride=64)
+    assert p["wavel"].shape == (16,) and p["sotf"].shape == (16, 251, 126) and p["templates"].shape == (4, 16)
+    assert [i.name for i in synth.config3(lam_stride=500)["ifus"]] == ["1C", "2A", "2B", "2C"]
+    assert len(synth.BANDS) == 12 and synth.band_wavelengths("2a").shape == (970,)
