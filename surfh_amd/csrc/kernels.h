@@ -4,37 +4,43 @@
 #include <stdint.h>
 
 // ---- spectral mix x OTF (T and C fused in the Fourier domain) -------------------------------
-// forward : spec[l] = sotf[l] * sum_t tpl[t,l] * mhat[t]        (spectroModel.py:161,166; mixing.py:232-245)
-// adjoint : madj[t] = sum_l tpl[t,l] * conj(sotf[l]) * spec[l]  (spectroModel.py:178,181; mixing.py:263-266)
-// planes are stored split: [plane][2 (re,im)][PL] floats, PL = KAP*KBP (zero padded).
-// T == 0 : no LMM, mhat has one plane per lambda.
+// forward : spec[k][l] = sotf[k][l] * sum_t tpl[t,l] * mhat[t][k]   (spectroModel.py:161,166; mixing.py:232-245)
+// adjoint : madj[t][k] = sum_l tpl[t,l] * conj(sotf[k][l]) * spec[k][l] (spectroModel.py:178,181; mixing.py:263-266)
+// Wavelength is the INNERMOST axis of every large array: spectra are [2 (re,im)][PL][LP] floats,
+// PL = KAP*KBP frequency bins, LP = padded number of owned planes (zero padded); mhat is [T][2][PL].
+// T == 0 (no LMM): mhat has the spectrum layout and the operation is element-wise.
 int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, const float *tpl, float *spec,
-                       int T, int L, long PL);
-int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *partial,
-                       float *madj, int T, int L, long PL, int nchunk);
+                       int T, long PL, int LP);
+int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj,
+                       int T, long PL, int LP);
 
-// ---- sparse (ELL) gather shared by all lambda planes -----------------------------------------
-// dst[b*dstStride + dst_off[r]] (+)= sum_{e<cnt[r]} val[e*R+r] * src[b*srcStride + col[e*R+r]]
-// One table serves: S + box-sum + slit window + decimation (forward), its exact transpose,
-// and the reference's interpolating gridding_t (adjoint_ref).
+// ---- sparse row gather, vectorised over wavelength ----------------------------------------------
+// dst[dst_off[r] + l] (+)= sum_{e<cnt[r]} val[r*W+e] * src[col[r*W+e] + l]   for l in [0, nlam)
+// One workgroup per (row, 1024-wavelength chunk): the table entries are workgroup-uniform (scalar
+// loads), every tap is a contiguous coalesced read.  One table format serves S + box-sum + slit
+// window + decimation (forward), its exact transpose, and the reference's interpolating
+// gridding_t (adjoint_ref).
 struct EllTable {
     int R = 0, W = 0;              // rows, max entries per row
     const int32_t *cnt = nullptr;  // [R]
-    const int32_t *col = nullptr;  // [W][R]
-    const float *val = nullptr;    // [W][R]
-    const int32_t *dst_off = nullptr;  // [R]
+    const int64_t *col = nullptr;  // [R][W]  source offset (floats) of wavelength 0
+    const float *val = nullptr;    // [R][W]
+    const int64_t *dst_off = nullptr;  // [R]
 };
-int launch_spmm_ell(hipStream_t s, const EllTable &t, const float *src, long srcStride, float *dst, long dstStride,
-                    int nblk, int accumulate);
+int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate);
+
+// [L][Na][Nb] (wavelength-major, the reference's cube layout) <-> [NBP][NAP][LP] (wavelength innermost)
+int launch_cube_to_lam_inner(hipStream_t s, const float *src, float *dst, int l0, int L, int na, int nb, int nap, int LP);
+int launch_cube_from_lam_inner(hipStream_t s, const float *src, float *dst, int l0, int L, int na, int nb, int nap, int LP);
 
 // ---- layout helpers -----------------------------------------------------------------------
 int launch_pad_planes(hipStream_t s, const float *src, float *dst, int B, int na, int nb, int nap, int nbp);
 int launch_unpad_planes(hipStream_t s, const float *src, float *dst, int B, int na, int nb, int nap, int nbp);
-// y[(ps*Ldet + l)*aout + a] = sum_k cpart[k][l*NP + ps*aout + a]
+// y[(ps*Ldet + l)*aout + a] = sum_k cpart[k][(ps*aout + a)*LdetP + l]
 int launch_y_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit, float *y, int PS, int Ldet,
-                        int aout, int NP);
-// ymat[l*NP + ps*aout + a] = y[(ps*Ldet + l)*aout + a]
-int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int NP);
+                        int aout, int LdetP);
+// ymat[(ps*aout + a)*LdetP + l] = y[(ps*Ldet + l)*aout + a]
+int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP);
 int launch_fill_zero(hipStream_t s, float *p, long n);
 
 // ---- CG vector kernels (qmm.lcg loop body; fusion_CT.py:16-43 priors) --------------------------

@@ -6,145 +6,179 @@ namespace {
 constexpr int TPB = 256;
 
 // ---------------------------------------------------------------------------------------------
-// spectral mix x OTF
+// spectral mix x OTF   (wavelength innermost: spectra are [2][PL][LP])
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void specmix_fwd_kernel(const float *__restrict__ mhat,
                                                           const float *__restrict__ sotf,
                                                           const float *__restrict__ tpl, float *__restrict__ spec,
-                                                          int T, int L, long PL) {
-    const long k4 = (long)blockIdx.x * TPB + threadIdx.x;
-    if (k4 * 4 >= PL) return;
-    const int l = blockIdx.y;
+                                                          int T, long PL, int LP) {
+    const int l4 = (blockIdx.x * TPB + threadIdx.x) * 4;
+    if (l4 >= LP) return;
+    const long k = blockIdx.y;
     float4 sr = make_float4(0.f, 0.f, 0.f, 0.f), si = sr;
     if (T > 0) {
         for (int t = 0; t < T; ++t) {
-            const float w = tpl[(long)t * L + l];
-            const float4 mr = *reinterpret_cast<const float4 *>(mhat + ((long)t * 2 + 0) * PL + k4 * 4);
-            const float4 mi = *reinterpret_cast<const float4 *>(mhat + ((long)t * 2 + 1) * PL + k4 * 4);
-            sr.x += w * mr.x; sr.y += w * mr.y; sr.z += w * mr.z; sr.w += w * mr.w;
-            si.x += w * mi.x; si.y += w * mi.y; si.z += w * mi.z; si.w += w * mi.w;
+            const float4 w = *reinterpret_cast<const float4 *>(tpl + (long)t * LP + l4);
+            const float mr = mhat[((long)t * 2 + 0) * PL + k];
+            const float mi = mhat[((long)t * 2 + 1) * PL + k];
+            sr.x += w.x * mr; sr.y += w.y * mr; sr.z += w.z * mr; sr.w += w.w * mr;
+            si.x += w.x * mi; si.y += w.y * mi; si.z += w.z * mi; si.w += w.w * mi;
         }
     } else {
-        sr = *reinterpret_cast<const float4 *>(mhat + ((long)l * 2 + 0) * PL + k4 * 4);
-        si = *reinterpret_cast<const float4 *>(mhat + ((long)l * 2 + 1) * PL + k4 * 4);
+        sr = *reinterpret_cast<const float4 *>(mhat + k * LP + l4);
+        si = *reinterpret_cast<const float4 *>(mhat + (PL + k) * LP + l4);
     }
-    const float4 hr = *reinterpret_cast<const float4 *>(sotf + ((long)l * 2 + 0) * PL + k4 * 4);
-    const float4 hi = *reinterpret_cast<const float4 *>(sotf + ((long)l * 2 + 1) * PL + k4 * 4);
+    const float4 hr = *reinterpret_cast<const float4 *>(sotf + k * LP + l4);
+    const float4 hi = *reinterpret_cast<const float4 *>(sotf + (PL + k) * LP + l4);
     float4 xr, xi;
     xr.x = hr.x * sr.x - hi.x * si.x; xi.x = hr.x * si.x + hi.x * sr.x;
     xr.y = hr.y * sr.y - hi.y * si.y; xi.y = hr.y * si.y + hi.y * sr.y;
     xr.z = hr.z * sr.z - hi.z * si.z; xi.z = hr.z * si.z + hi.z * sr.z;
     xr.w = hr.w * sr.w - hi.w * si.w; xi.w = hr.w * si.w + hi.w * sr.w;
-    *reinterpret_cast<float4 *>(spec + ((long)l * 2 + 0) * PL + k4 * 4) = xr;
-    *reinterpret_cast<float4 *>(spec + ((long)l * 2 + 1) * PL + k4 * 4) = xi;
+    *reinterpret_cast<float4 *>(spec + k * LP + l4) = xr;
+    *reinterpret_cast<float4 *>(spec + (PL + k) * LP + l4) = xi;
 }
 
-// partial[chunk][t][c][PL] = sum_{l in chunk} tpl[t,l] conj(H[l]) Y[l], templates t0..t0+3
-__global__ __launch_bounds__(TPB) void specmix_adj_partial_kernel(const float *__restrict__ spec,
-                                                                  const float *__restrict__ sotf,
-                                                                  const float *__restrict__ tpl,
-                                                                  float *__restrict__ partial, int T, int t0, int L,
-                                                                  long PL, int nchunk) {
-    const long k4 = (long)blockIdx.x * TPB + threadIdx.x;
-    if (k4 * 4 >= PL) return;
-    const int ch = blockIdx.y;
-    const int per = (L + nchunk - 1) / nchunk;
-    const int l0 = ch * per, l1 = min(L, l0 + per);
-    float4 ar[4], ai[4];
+constexpr int MAXT = 8;
+
+// one workgroup per frequency bin k: madj[t][c][k] = sum_l tpl[t][l] (conj(H) Y)[c][k][l]
+__global__ __launch_bounds__(TPB) void specmix_adj_kernel(const float *__restrict__ spec,
+                                                          const float *__restrict__ sotf,
+                                                          const float *__restrict__ tpl, float *__restrict__ madj,
+                                                          int T, long PL, int LP) {
+    const long k = blockIdx.x;
+    float ar[MAXT], ai[MAXT];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) ar[g] = ai[g] = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int l = l0; l < l1; ++l) {
-        const float4 hr = *reinterpret_cast<const float4 *>(sotf + ((long)l * 2 + 0) * PL + k4 * 4);
-        const float4 hi = *reinterpret_cast<const float4 *>(sotf + ((long)l * 2 + 1) * PL + k4 * 4);
-        const float4 yr = *reinterpret_cast<const float4 *>(spec + ((long)l * 2 + 0) * PL + k4 * 4);
-        const float4 yi = *reinterpret_cast<const float4 *>(spec + ((long)l * 2 + 1) * PL + k4 * 4);
+    for (int t = 0; t < MAXT; ++t) ar[t] = ai[t] = 0.f;
+    for (int l4 = threadIdx.x * 4; l4 < LP; l4 += TPB * 4) {
+        const float4 hr = *reinterpret_cast<const float4 *>(sotf + k * LP + l4);
+        const float4 hi = *reinterpret_cast<const float4 *>(sotf + (PL + k) * LP + l4);
+        const float4 yr = *reinterpret_cast<const float4 *>(spec + k * LP + l4);
+        const float4 yi = *reinterpret_cast<const float4 *>(spec + (PL + k) * LP + l4);
         float4 pr, pi;
         pr.x = hr.x * yr.x + hi.x * yi.x; pi.x = hr.x * yi.x - hi.x * yr.x;
         pr.y = hr.y * yr.y + hi.y * yi.y; pi.y = hr.y * yi.y - hi.y * yr.y;
         pr.z = hr.z * yr.z + hi.z * yi.z; pi.z = hr.z * yi.z - hi.z * yr.z;
         pr.w = hr.w * yr.w + hi.w * yi.w; pi.w = hr.w * yi.w - hi.w * yr.w;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float w = (t0 + g < T) ? tpl[(long)(t0 + g) * L + l] : 0.f;
-            ar[g].x += w * pr.x; ar[g].y += w * pr.y; ar[g].z += w * pr.z; ar[g].w += w * pr.w;
-            ai[g].x += w * pi.x; ai[g].y += w * pi.y; ai[g].z += w * pi.z; ai[g].w += w * pi.w;
-        }
+        for (int t = 0; t < MAXT; ++t)
+            if (t < T) {
+                const float4 w = *reinterpret_cast<const float4 *>(tpl + (long)t * LP + l4);
+                ar[t] += w.x * pr.x + w.y * pr.y + w.z * pr.z + w.w * pr.w;
+                ai[t] += w.x * pi.x + w.y * pi.y + w.z * pi.z + w.w * pi.w;
+            }
     }
+    __shared__ float red[TPB / 64][2 * MAXT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-        if (t0 + g < T) {
-            float *p = partial + (((long)ch * T + (t0 + g)) * 2) * PL + k4 * 4;
-            *reinterpret_cast<float4 *>(p) = ar[g];
-            *reinterpret_cast<float4 *>(p + PL) = ai[g];
+    for (int t = 0; t < MAXT; ++t) {
+        float a = ar[t], b = ai[t];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            b += __shfl_down(b, o, 64);
         }
-}
-
-// madj[i] = sum_ch partial[ch][i],  i over T*2*PL
-__global__ __launch_bounds__(TPB) void chunk_reduce_kernel(const float *__restrict__ partial, float *__restrict__ out,
-                                                           long n, int nchunk) {
-    const long i4 = (long)blockIdx.x * TPB + threadIdx.x;
-    if (i4 * 4 >= n) return;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int c = 0; c < nchunk; ++c) {
-        const float4 v = *reinterpret_cast<const float4 *>(partial + (long)c * n + i4 * 4);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        if (lane == 0) {
+            red[wv][2 * t] = a;
+            red[wv][2 * t + 1] = b;
+        }
     }
-    *reinterpret_cast<float4 *>(out + i4 * 4) = a;
+    __syncthreads();
+    if (threadIdx.x < 2 * T) {
+        float s = 0.f;
+        for (int w = 0; w < TPB / 64; ++w) s += red[w][threadIdx.x];
+        const int t = threadIdx.x >> 1, c = threadIdx.x & 1;
+        madj[((long)t * 2 + c) * PL + k] = s;
+    }
 }
 
-// no-LMM adjoint: out[l] = conj(H[l]) Y[l]
+// no-LMM adjoint: out[c][k][l] = (conj(H) Y)[c][k][l]
 __global__ __launch_bounds__(TPB) void specmix_adj_plane_kernel(const float *__restrict__ spec,
                                                                 const float *__restrict__ sotf,
-                                                                float *__restrict__ out, long PL) {
-    const long k4 = (long)blockIdx.x * TPB + threadIdx.x;
-    if (k4 * 4 >= PL) return;
-    const long l = blockIdx.y;
-    const float4 hr = *reinterpret_cast<const float4 *>(sotf + (l * 2 + 0) * PL + k4 * 4);
-    const float4 hi = *reinterpret_cast<const float4 *>(sotf + (l * 2 + 1) * PL + k4 * 4);
-    const float4 yr = *reinterpret_cast<const float4 *>(spec + (l * 2 + 0) * PL + k4 * 4);
-    const float4 yi = *reinterpret_cast<const float4 *>(spec + (l * 2 + 1) * PL + k4 * 4);
+                                                                float *__restrict__ out, long PL, int LP) {
+    const int l4 = (blockIdx.x * TPB + threadIdx.x) * 4;
+    if (l4 >= LP) return;
+    const long k = blockIdx.y;
+    const float4 hr = *reinterpret_cast<const float4 *>(sotf + k * LP + l4);
+    const float4 hi = *reinterpret_cast<const float4 *>(sotf + (PL + k) * LP + l4);
+    const float4 yr = *reinterpret_cast<const float4 *>(spec + k * LP + l4);
+    const float4 yi = *reinterpret_cast<const float4 *>(spec + (PL + k) * LP + l4);
     float4 pr, pi;
     pr.x = hr.x * yr.x + hi.x * yi.x; pi.x = hr.x * yi.x - hi.x * yr.x;
     pr.y = hr.y * yr.y + hi.y * yi.y; pi.y = hr.y * yi.y - hi.y * yr.y;
     pr.z = hr.z * yr.z + hi.z * yi.z; pi.z = hr.z * yi.z - hi.z * yr.z;
     pr.w = hr.w * yr.w + hi.w * yi.w; pi.w = hr.w * yi.w - hi.w * yr.w;
-    *reinterpret_cast<float4 *>(out + (l * 2 + 0) * PL + k4 * 4) = pr;
-    *reinterpret_cast<float4 *>(out + (l * 2 + 1) * PL + k4 * 4) = pi;
+    *reinterpret_cast<float4 *>(out + k * LP + l4) = pr;
+    *reinterpret_cast<float4 *>(out + (PL + k) * LP + l4) = pi;
 }
 
 // ---------------------------------------------------------------------------------------------
-// ELL sparse gather, LB lambda planes per thread so one table read serves LB planes
+// sparse row gather vectorised over wavelength: one workgroup = one table row x 1024 wavelengths
 // ---------------------------------------------------------------------------------------------
-template <int LB>
-__global__ __launch_bounds__(TPB) void spmm_ell_kernel(EllTable t, const float *__restrict__ src, long srcStride,
-                                                       float *__restrict__ dst, long dstStride, int nblk,
-                                                       int accumulate) {
-    const int r = blockIdx.x * TPB + threadIdx.x;
-    if (r >= t.R) return;
-    const int b0 = blockIdx.y * LB;
-    const float *sp[LB];
-#pragma unroll
-    for (int l = 0; l < LB; ++l) sp[l] = src + (long)min(b0 + l, nblk - 1) * srcStride;
-    float acc[LB];
-#pragma unroll
-    for (int l = 0; l < LB; ++l) acc[l] = 0.f;
+__global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float *__restrict__ src,
+                                                        float *__restrict__ dst, int nlam, int accumulate) {
+    const int r = blockIdx.x;
+    const int l4 = (blockIdx.y * TPB + threadIdx.x) * 4;
+    if (l4 >= nlam) return;
     const int n = t.cnt[r];
-    for (int e = 0; e < n; ++e) {
-        const int c = t.col[(long)e * t.R + r];
-        const float v = t.val[(long)e * t.R + r];
-#pragma unroll
-        for (int l = 0; l < LB; ++l) acc[l] += v * sp[l][c];
+    const int64_t *col = t.col + (long)r * t.W;
+    const float *val = t.val + (long)r * t.W;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = 0;
+    for (; e + 4 <= n; e += 4) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+        const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
+        const float4 x2 = *reinterpret_cast<const float4 *>(src + col[e + 2] + l4);
+        const float4 x3 = *reinterpret_cast<const float4 *>(src + col[e + 3] + l4);
+        const float v0 = val[e], v1 = val[e + 1], v2 = val[e + 2], v3 = val[e + 3];
+        acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+        acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
+        acc.x += v2 * x2.x; acc.y += v2 * x2.y; acc.z += v2 * x2.z; acc.w += v2 * x2.w;
+        acc.x += v3 * x3.x; acc.y += v3 * x3.y; acc.z += v3 * x3.z; acc.w += v3 * x3.w;
     }
-    const long off = t.dst_off[r];
-#pragma unroll
-    for (int l = 0; l < LB; ++l)
-        if (b0 + l < nblk) {
-            float *p = dst + (long)(b0 + l) * dstStride + off;
-            if (accumulate)
-                *p += acc[l];
-            else
-                *p = acc[l];
-        }
+    for (; e < n; ++e) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+        const float v0 = val[e];
+        acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+    }
+    float4 *p = reinterpret_cast<float4 *>(dst + t.dst_off[r] + l4);
+    if (accumulate) {
+        const float4 o = *p;
+        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+    }
+    *p = acc;
+}
+
+// [L][na][nb] planes l0.. of a wavelength-major cube -> [nb][nap][LP] wavelength innermost (32x32 LDS tile transpose)
+__global__ __launch_bounds__(256) void cube_to_lam_inner_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                int l0, int L, int na, int nb, int nap, int LP) {
+    __shared__ float tile[32][33];
+    const int a = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int l = blockIdx.y * 32 + i, b = blockIdx.x * 32 + tx;
+        tile[i][tx] = (l < L && b < nb) ? src[((long)(l0 + l) * na + a) * nb + b] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int b = blockIdx.x * 32 + i, l = blockIdx.y * 32 + tx;
+        if (b < nb && l < L) dst[((long)b * nap + a) * LP + l] = tile[tx][i];
+    }
+}
+
+__global__ __launch_bounds__(256) void cube_from_lam_inner_kernel(const float *__restrict__ src, float *__restrict__ dst,
+                                                                  int l0, int L, int na, int nb, int nap, int LP) {
+    __shared__ float tile[32][33];
+    const int a = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int b = blockIdx.x * 32 + i, l = blockIdx.y * 32 + tx;
+        tile[i][tx] = (b < nb && l < L) ? src[((long)b * nap + a) * LP + l] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int l = blockIdx.y * 32 + i, b = blockIdx.x * 32 + tx;
+        if (l < L && b < nb) dst[((long)(l0 + l) * na + a) * nb + b] = tile[tx][i];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -166,27 +200,27 @@ __global__ __launch_bounds__(TPB) void unpad_planes_kernel(const float *__restri
     if (j < nb) dst[(b * na + i) * nb + j] = src[(b * nap + i) * nbp + j];
 }
 
+// thread index runs over l fastest so the slab reads are coalesced
 __global__ __launch_bounds__(TPB) void y_from_cpart_kernel(const float *__restrict__ cpart, long slab, int nsplit,
-                                                           float *__restrict__ y, int PS, int Ldet, int aout, int NP) {
-    const long i = (long)blockIdx.x * TPB + threadIdx.x;
-    const long n = (long)PS * Ldet * aout;
-    if (i >= n) return;
-    const int a = i % aout;
-    const int l = (i / aout) % Ldet;
-    const int ps = i / ((long)aout * Ldet);
-    const long src = (long)l * NP + ps * aout + a;
+                                                           float *__restrict__ y, int PS, int Ldet, int aout,
+                                                           int LdetP) {
+    const int l = blockIdx.x * TPB + threadIdx.x;
+    const int n = blockIdx.y;           // ps*aout + a
+    if (l >= Ldet) return;
+    const int ps = n / aout, a = n % aout;
+    const long src = (long)n * LdetP + l;
     float s = 0.f;
     for (int k = 0; k < nsplit; ++k) s += cpart[k * slab + src];
-    y[i] = s;
+    y[((long)ps * Ldet + l) * aout + a] = s;
 }
 
 __global__ __launch_bounds__(TPB) void ymat_from_y_kernel(const float *__restrict__ y, float *__restrict__ ymat, int PS,
-                                                          int Ldet, int aout, int NP) {
-    const int n = blockIdx.x * TPB + threadIdx.x;
-    const int l = blockIdx.y;
-    if (n >= PS * aout) return;
+                                                          int Ldet, int aout, int LdetP) {
+    const int l = blockIdx.x * TPB + threadIdx.x;
+    const int n = blockIdx.y;
+    if (l >= Ldet) return;
     const int ps = n / aout, a = n % aout;
-    ymat[(long)l * NP + n] = y[((long)ps * Ldet + l) * aout + a];
+    ymat[(long)n * LdetP + l] = y[((long)ps * Ldet + l) * aout + a];
 }
 
 __global__ __launch_bounds__(TPB) void fill_zero_kernel(float *p, long n) {
@@ -297,36 +331,42 @@ constexpr int DOT_BLOCKS = 512;
 }  // namespace
 
 int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, const float *tpl, float *spec, int T,
-                       int L, long PL) {
-    dim3 grid((unsigned)((PL / 4 + TPB - 1) / TPB), L);
-    hipLaunchKernelGGL(specmix_fwd_kernel, grid, dim3(TPB), 0, s, mhat, sotf, tpl, spec, T, L, PL);
+                       long PL, int LP) {
+    if (T > MAXT) return (int)hipErrorInvalidValue;
+    dim3 grid((LP / 4 + TPB - 1) / TPB, (unsigned)PL);
+    hipLaunchKernelGGL(specmix_fwd_kernel, grid, dim3(TPB), 0, s, mhat, sotf, tpl, spec, T, PL, LP);
     return (int)hipGetLastError();
 }
 
-int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *partial,
-                       float *madj, int T, int L, long PL, int nchunk) {
+int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj, int T,
+                       long PL, int LP) {
+    if (T > MAXT) return (int)hipErrorInvalidValue;
     if (T == 0) {
-        dim3 grid((unsigned)((PL / 4 + TPB - 1) / TPB), L);
-        hipLaunchKernelGGL(specmix_adj_plane_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL);
-        return (int)hipGetLastError();
+        dim3 grid((LP / 4 + TPB - 1) / TPB, (unsigned)PL);
+        hipLaunchKernelGGL(specmix_adj_plane_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP);
+    } else {
+        hipLaunchKernelGGL(specmix_adj_kernel, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
     }
-    dim3 grid((unsigned)((PL / 4 + TPB - 1) / TPB), nchunk);
-    for (int t0 = 0; t0 < T; t0 += 4)
-        hipLaunchKernelGGL(specmix_adj_partial_kernel, grid, dim3(TPB), 0, s, spec, sotf, tpl, partial, T, t0, L, PL,
-                           nchunk);
-    const long n = (long)T * 2 * PL;
-    hipLaunchKernelGGL(chunk_reduce_kernel, dim3((unsigned)((n / 4 + TPB - 1) / TPB)), dim3(TPB), 0, s, partial, madj,
-                       n, nchunk);
     return (int)hipGetLastError();
 }
 
-int launch_spmm_ell(hipStream_t s, const EllTable &t, const float *src, long srcStride, float *dst, long dstStride,
-                    int nblk, int accumulate) {
-    if (t.R == 0 || nblk == 0) return 0;
-    constexpr int LB = 4;
-    dim3 grid((t.R + TPB - 1) / TPB, (nblk + LB - 1) / LB);
-    hipLaunchKernelGGL((spmm_ell_kernel<LB>), grid, dim3(TPB), 0, s, t, src, srcStride, dst, dstStride, nblk,
-                       accumulate);
+int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate) {
+    if (t.R == 0 || nlam <= 0) return 0;
+    if (nlam % 4) return (int)hipErrorInvalidValue;
+    dim3 grid(t.R, (nlam / 4 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate);
+    return (int)hipGetLastError();
+}
+
+int launch_cube_to_lam_inner(hipStream_t s, const float *src, float *dst, int l0, int L, int na, int nb, int nap, int LP) {
+    dim3 grid((nb + 31) / 32, (L + 31) / 32, na);
+    hipLaunchKernelGGL(cube_to_lam_inner_kernel, grid, dim3(256), 0, s, src, dst, l0, L, na, nb, nap, LP);
+    return (int)hipGetLastError();
+}
+
+int launch_cube_from_lam_inner(hipStream_t s, const float *src, float *dst, int l0, int L, int na, int nb, int nap, int LP) {
+    dim3 grid((nb + 31) / 32, (L + 31) / 32, na);
+    hipLaunchKernelGGL(cube_from_lam_inner_kernel, grid, dim3(256), 0, s, src, dst, l0, L, na, nb, nap, LP);
     return (int)hipGetLastError();
 }
 
@@ -343,16 +383,15 @@ int launch_unpad_planes(hipStream_t s, const float *src, float *dst, int B, int 
 }
 
 int launch_y_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit, float *y, int PS, int Ldet,
-                        int aout, int NP) {
-    const long n = (long)PS * Ldet * aout;
-    hipLaunchKernelGGL(y_from_cpart_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, cpart, slab,
-                       nsplit, y, PS, Ldet, aout, NP);
+                        int aout, int LdetP) {
+    dim3 grid((Ldet + TPB - 1) / TPB, PS * aout);
+    hipLaunchKernelGGL(y_from_cpart_kernel, grid, dim3(TPB), 0, s, cpart, slab, nsplit, y, PS, Ldet, aout, LdetP);
     return (int)hipGetLastError();
 }
 
-int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int NP) {
-    dim3 grid((PS * aout + TPB - 1) / TPB, Ldet);
-    hipLaunchKernelGGL(ymat_from_y_kernel, grid, dim3(TPB), 0, s, y, ymat, PS, Ldet, aout, NP);
+int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP) {
+    dim3 grid((Ldet + TPB - 1) / TPB, PS * aout);
+    hipLaunchKernelGGL(ymat_from_y_kernel, grid, dim3(TPB), 0, s, y, ymat, PS, Ldet, aout, LdetP);
     return (int)hipGetLastError();
 }
 

@@ -2,13 +2,21 @@
 // the forward / adjoint pipelines and the CG loop.  All device work goes through
 // gemm_f32.hip and kernels.hip on one HIP stream.
 //
+// Data layout: WAVELENGTH IS THE INNERMOST AXIS of every large device array (lambda is the batch
+// dimension of every stage of the reference, so making it contiguous turns every kernel into
+// coalesced streaming and every dense stage into one large GEMM):
+//   spectra  sotf, spec      [2 (re,im)][KAP][KBP][LP]
+//   cube     blurred / g     [NBP (beta)][NAP (alpha)][LP]
+//   operand  Xs (per channel)[NP = (p,s,a)][n_beta_slit][LinP]      K index = (b', lambda)
+// LP = owned planes padded to 128, all other dims padded to 64, padding is zero.
+//
 // Pipeline (per plan = per GPU), reference citations relative to /root/reference:
 //   forward  (spectroModel.py:158-170, spectroModelChannel.py:215-231)
-//     maps --pad--> rfft2 (2 GEMMs) --> mhat[T]
-//     spec[l]   = sotf[l] * sum_t tpl[t,l] mhat[t]                    (T and C fused, Fourier domain)
-//     blurred   = irfft2(spec)  (2 GEMMs per plane)
-//     per channel:  Xs[(l,b'),(p,s,a)] = G * blurred[l]               (S + box-sum + L + decimation, ELL gather)
-//                   y[(p,s),l',a] = sum_{(l,b')} W[l',(l,b')] Xs      (R + beta-sum, one GEMM, split-K)
+//     maps --pad--> rfft2 (2 small GEMMs) --> mhat[T][2][KAP][KBP]
+//     spec[k][l] = sotf[k][l] * sum_t tpl[t,l] mhat[t][k]             (T and C fused, Fourier domain)
+//     blurred    = irfft2(spec): two GEMMs with the DFT matrices as the A operand
+//     per channel:  Xs[(p,s,a)][b'][l] = G * blurred                  (S + box-sum + L + decimation, row gather)
+//                   y^T[(p,s,a)][l'] = Xs * W^T                       (R + beta-sum, one GEMM, split-K)
 //   adjoint  (spectroModel.py:173-185, spectroModelChannel.py:234-264): the transposes, in reverse.
 #include <hip/hip_runtime.h>
 
@@ -54,14 +62,20 @@ inline int pad64(int n) { return (n + 63) / 64 * 64; }
 
 struct DevEll {
     EllTable t;
-    int32_t *cnt = nullptr, *col = nullptr, *dst = nullptr;
+    int32_t *cnt = nullptr;
+    int64_t *col = nullptr, *dst = nullptr;
     float *val = nullptr;
 };
 
 struct Channel {
     int ws0 = 0, ws1 = 0, Lin = 0, P = 0, S = 0, Ldet = 0, aout = 0, srf = 0, na = 0, nb = 0, alpha0 = 0, nas = 0,
         nbs = 0;
-    int KP = 0, NP = 0, LdetP = 0, splitK = 1;
+    int ws0a = 0;      // window start relative to the plan's first plane, rounded down to a multiple of 4
+    int LinA = 0;      // planes from ws0a to the window end
+    int LinP = 0;      // LinA padded to 64
+    int shift = 0;     // (ws0 - lo) - ws0a
+    int nlam = 0;      // LinA rounded up to 4: wavelengths the gather kernels process
+    int K = 0, NP = 0, LdetP = 0, splitK = 1;
     long yoff = 0, ysize = 0;
     float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
     DevEll fwd, adjT, adjRef;
@@ -81,13 +95,11 @@ struct surfh_plan {
     bool own_stream = false;
     int Na = 0, Nb = 0, Lc = 0, T = 0, NAP = 0, NBP = 0, KAP = 0, KBP = 0;
     long PL = 0, PLc = 0;
-    int lo = 0, hi = 0, Lown = 0;
-    int nplanes_m = 0;   // planes of mhat / maps_pad: T, or Lown without LMM
+    int lo = 0, hi = 0, Lown = 0, LP = 0;
     float *sotf = nullptr, *tpl = nullptr, *mhat = nullptr, *spec = nullptr, *ycol = nullptr, *cube = nullptr,
-          *partial = nullptr, *maps_pad = nullptr;
-    float *Fi = nullptr, *Gi = nullptr, *Gf = nullptr, *Ff = nullptr;
+          *maps_pad = nullptr, *ycol_maps = nullptr;
+    float *Fi = nullptr, *Gi = nullptr, *Gf = nullptr, *Ff = nullptr, *GiT = nullptr, *GfT = nullptr;
     float *io_x = nullptr, *io_y = nullptr;
-    int nchunk = 32;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
     // CG
@@ -157,23 +169,24 @@ int dev_upload(Tp **p, const std::vector<Tp> &h) {
     return 0;
 }
 
-// host-side ELL (rows = outputs)
+// host-side sparse rows: (source index, weight) lists + one destination per row
 struct HostEll {
-    std::vector<std::vector<std::pair<int32_t, float>>> rows;   // (col, val)
-    std::vector<int32_t> dst;
+    std::vector<std::vector<std::pair<int64_t, float>>> rows;
+    std::vector<int64_t> dst;
 };
 
 int upload_ell(const HostEll &h, DevEll *d) {
     const int R = (int)h.rows.size();
-    int W = 0;
+    int W = 1;
     for (auto &r : h.rows) W = std::max(W, (int)r.size());
-    std::vector<int32_t> cnt(R), col((size_t)R * std::max(W, 1), 0);
-    std::vector<float> val((size_t)R * std::max(W, 1), 0.f);
+    std::vector<int32_t> cnt(R);
+    std::vector<int64_t> col((size_t)R * W, 0);
+    std::vector<float> val((size_t)R * W, 0.f);
     for (int r = 0; r < R; ++r) {
         cnt[r] = (int32_t)h.rows[r].size();
         for (int e = 0; e < cnt[r]; ++e) {
-            col[(size_t)e * R + r] = h.rows[r][e].first;
-            val[(size_t)e * R + r] = h.rows[r][e].second;
+            col[(size_t)r * W + e] = h.rows[r][e].first;
+            val[(size_t)r * W + e] = h.rows[r][e].second;
         }
     }
     if (dev_upload(&d->cnt, cnt) || dev_upload(&d->col, col) || dev_upload(&d->val, val) || dev_upload(&d->dst, h.dst))
@@ -219,7 +232,13 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
         return fail("channel table pointer is NULL");
     for (int s = 0; s < c->S; ++s)
         if (d.slit_beta0[s] < 0 || d.slit_beta0[s] + c->nbs > c->nb) return fail("slit %d beta window outside the local grid", s);
-    c->KP = pad64(c->Lin * c->nbs);
+    // wavelength window inside the plan's planes, start aligned to 4 floats for 16-byte vector access
+    c->ws0a = ((c->ws0 - p->lo) / 4) * 4;
+    c->shift = (c->ws0 - p->lo) - c->ws0a;
+    c->LinA = (c->ws1 - p->lo) - c->ws0a;
+    c->LinP = pad64(c->LinA);
+    c->nlam = (c->LinA + 3) / 4 * 4;
+    c->K = c->nbs * c->LinP;
     c->NP = pad64(c->P * c->S * c->aout);
     c->LdetP = pad64(c->Ldet);
     c->ysize = (long)c->P * c->S * c->Ldet * c->aout;
@@ -231,10 +250,15 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
         if (d.grid_i0[i] < 0 || d.grid_i0[i] > p->Na - 2 || d.grid_i1[i] < 0 || d.grid_i1[i] > p->Nb - 2)
             return fail("bilinear index out of range at local pixel %ld", i);
 
-    // ---- forward ELL: rows (p, a, j-order over (s,b')) ------------------------------------
+    const int64_t LP = p->LP;
+    auto pix_off = [&](int ia, int ib) -> int64_t { return ((int64_t)ib * p->NAP + ia) * LP + c->ws0a; };
+    auto xs_off = [&](int pt, int s, int a, int b) -> int64_t {
+        return ((int64_t)((pt * c->S + s) * c->aout + a)) * c->K + (int64_t)b * c->LinP;
+    };
+
+    // ---- forward rows (p, a, j-order over (s,b')): S + box-sum + slit window + decimation -------
     HostEll f;
-    // column -> (slit, b') pairs, in ascending column order
-    std::vector<std::vector<std::pair<int, int>>> colslit(c->nb);
+    std::vector<std::vector<std::pair<int, int>>> colslit(c->nb);   // local column -> (slit, b')
     for (int s = 0; s < c->S; ++s)
         for (int b = 0; b < c->nbs; ++b) colslit[d.slit_beta0[s] + b].push_back({s, b});
     for (int pt = 0; pt < c->P; ++pt)
@@ -243,7 +267,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                 for (auto &sb : colslit[j]) {
                     const int s = sb.first, b = sb.second;
                     const double ws = d.slit_weights[(long)s * c->nbs + b];
-                    std::vector<std::pair<int32_t, float>> row;
+                    std::vector<std::pair<int64_t, float>> row;
                     row.reserve(4 * c->srf);
                     for (int r = 0; r < c->srf; ++r) {
                         const int i = (c->alpha0 + a * c->srf + r) % c->na;
@@ -251,23 +275,22 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                         const int i0 = d.grid_i0[li], i1 = d.grid_i1[li];
                         const double y0 = d.grid_y0[li], y1 = d.grid_y1[li];
                         const double w[4] = {(1. - y0) * (1. - y1), (1. - y0) * y1, y0 * (1. - y1), y0 * y1};
-                        const int32_t base = i0 * p->NBP + i1;
-                        const int32_t off[4] = {base, base + 1, base + p->NBP, base + p->NBP + 1};
-                        for (int k = 0; k < 4; ++k) row.push_back({off[k], (float)(w[k] * ws)});
+                        const int da[4] = {0, 0, 1, 1}, db[4] = {0, 1, 0, 1};
+                        for (int k = 0; k < 4; ++k) row.push_back({pix_off(i0 + da[k], i1 + db[k]), (float)(w[k] * ws)});
                     }
                     f.rows.push_back(std::move(row));
-                    f.dst.push_back((int32_t)((long)b * c->NP + ((long)pt * c->S + s) * c->aout + a));
+                    f.dst.push_back(xs_off(pt, s, a, b));
                 }
     if (upload_ell(f, &c->fwd)) return 1;
 
     // ---- exact transpose: rows = touched cube pixels ------------------------------------------
     {
-        std::map<int32_t, std::map<int32_t, double>> tr;   // pixel -> (src -> weight)
+        std::map<int64_t, std::map<int64_t, double>> tr;   // pixel offset -> (Xs offset -> weight)
         for (size_t r = 0; r < f.rows.size(); ++r)
             for (auto &e : f.rows[r]) tr[e.first][f.dst[r]] += (double)e.second;
         HostEll t;
         for (auto &px : tr) {
-            std::vector<std::pair<int32_t, float>> row;
+            std::vector<std::pair<int64_t, float>> row;
             for (auto &e : px.second) row.push_back({e.first, (float)e.second});
             t.rows.push_back(std::move(row));
             t.dst.push_back(px.first);
@@ -278,15 +301,15 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     // ---- reference-compatible back-interpolation (gridding_t) ---------------------------------
     c->has_ref = d.gt_i0 && d.gt_i1 && d.gt_y0 && d.gt_y1 && d.gt_inside;
     if (c->has_ref) {
-        // local row i' -> list of decimated rows a whose box window contains it
+        // local row i' -> decimated rows a whose box window contains it
         std::vector<std::vector<int>> arow(c->na);
         for (int a = 0; a < c->aout; ++a)
             for (int r = 0; r < c->srf; ++r) arow[(c->alpha0 + a * c->srf + r) % c->na].push_back(a);
         HostEll t;
         const long npix = (long)p->Na * p->Nb;
-        for (int ia = 0; ia < p->Na; ++ia)
-            for (int ib = 0; ib < p->Nb; ++ib) {
-                std::map<int32_t, double> m;
+        for (int ib = 0; ib < p->Nb; ++ib)
+            for (int ia = 0; ia < p->Na; ++ia) {
+                std::map<int64_t, double> m;
                 for (int pt = 0; pt < c->P; ++pt) {
                     const long gi = (long)pt * npix + (long)ia * p->Nb + ib;
                     if (!d.gt_inside[gi]) continue;
@@ -297,47 +320,46 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                     const int li[4] = {i0, i0, i0 + 1, i0 + 1}, lj[4] = {i1, i1 + 1, i1, i1 + 1};
                     for (int k = 0; k < 4; ++k)
                         for (int a : arow[li[k]])
-                            for (auto &sb : colslit[lj[k]]) {
-                                const double ws = d.slit_weights[(long)sb.first * c->nbs + sb.second];
-                                m[(int32_t)((long)sb.second * c->NP + ((long)pt * c->S + sb.first) * c->aout + a)] += w[k] * ws;
-                            }
+                            for (auto &sb : colslit[lj[k]])
+                                m[xs_off(pt, sb.first, a, sb.second)] += w[k] * d.slit_weights[(long)sb.first * c->nbs + sb.second];
                 }
                 if (m.empty()) continue;
-                std::vector<std::pair<int32_t, float>> row;
+                std::vector<std::pair<int64_t, float>> row;
                 for (auto &e : m) row.push_back({e.first, (float)e.second});
                 t.rows.push_back(std::move(row));
-                t.dst.push_back((int32_t)(ia * p->NBP + ib));
+                t.dst.push_back(pix_off(ia, ib));
             }
         if (upload_ell(t, &c->adjRef)) return 1;
     }
 
-    // ---- spectral PSF as GEMM operands ----------------------------------------------------------
+    // ---- spectral PSF as GEMM operands: W[l'][b'*LinP + shift + l] = wpsf[l'][l][b'] -------------
     {
-        const long K = (long)c->Lin * c->nbs;
-        std::vector<float> W((size_t)c->LdetP * c->KP, 0.f), Wt((size_t)c->KP * c->LdetP, 0.f);
+        std::vector<float> W((size_t)c->LdetP * c->K, 0.f), Wt((size_t)c->K * c->LdetP, 0.f);
         for (int l = 0; l < c->Ldet; ++l)
-            for (long k = 0; k < K; ++k) {
-                const float v = (float)d.wpsf[(long)l * K + k];
-                W[(size_t)l * c->KP + k] = v;
-                Wt[(size_t)k * c->LdetP + l] = v;
-            }
+            for (int lam = 0; lam < c->Lin; ++lam)
+                for (int b = 0; b < c->nbs; ++b) {
+                    const float v = (float)d.wpsf[((long)l * c->Lin + lam) * c->nbs + b];
+                    const size_t k = (size_t)b * c->LinP + c->shift + lam;
+                    W[(size_t)l * c->K + k] = v;
+                    Wt[k * c->LdetP + l] = v;
+                }
         if (dev_upload(&c->W, W) || dev_upload(&c->Wt, Wt)) return 1;
     }
-    if (dev_alloc(&c->Xs, (size_t)c->KP * c->NP)) return 1;
-    HIP_OK(hipMemset(c->Xs, 0, (size_t)c->KP * c->NP * sizeof(float)));
-    if (dev_alloc(&c->ymat, (size_t)c->LdetP * c->NP)) return 1;
-    HIP_OK(hipMemset(c->ymat, 0, (size_t)c->LdetP * c->NP * sizeof(float)));
+    if (dev_alloc(&c->Xs, (size_t)c->NP * c->K)) return 1;
+    HIP_OK(hipMemset(c->Xs, 0, (size_t)c->NP * c->K * sizeof(float)));
+    if (dev_alloc(&c->ymat, (size_t)c->NP * c->LdetP)) return 1;
+    HIP_OK(hipMemset(c->ymat, 0, (size_t)c->NP * c->LdetP * sizeof(float)));
     return 0;
 }
 
 int pick_split(const Channel &c, int forced) {
-    if (forced > 0) return (c.KP % (16 * forced) == 0) ? forced : 1;
-    const int bm = (c.LdetP % 128 == 0) ? 128 : 64, bn = (c.NP % 128 == 0) ? 128 : 64;
-    const long tiles = (long)(c.LdetP / bm) * (c.NP / bn);
+    if (forced > 0) return (c.K % (16 * forced) == 0) ? forced : 1;
+    const int bm = (c.NP % 128 == 0) ? 128 : 64, bn = (c.LdetP % 128 == 0) ? 128 : 64;
+    const long tiles = (long)(c.NP / bm) * (c.LdetP / bn);
     int best = 1;
     for (int s : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
-        if (c.KP % (16 * s)) continue;
-        if (c.KP / s < 256) break;
+        if (c.K % (16 * s)) continue;
+        if (c.K / s < 256) break;
         best = s;
         if (tiles * s >= 768) break;
     }
@@ -345,10 +367,11 @@ int pick_split(const Channel &c, int forced) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// DFT matrices (ortho), see the sign/weight conventions in DESIGN.md
+// DFT matrices (ortho).  Forward r2c along beta then c2c along alpha; inverse c2c along alpha then
+// c2r along beta with Hermitian weights w_k (1 for k=0 and Nyquist, else 2) -- numpy's rfft2/irfft2.
 // ---------------------------------------------------------------------------------------------
 void build_dft(const surfh_plan *p, std::vector<float> &Fi, std::vector<float> &Gi, std::vector<float> &Gf,
-               std::vector<float> &Ff) {
+               std::vector<float> &Ff, std::vector<float> &GiT, std::vector<float> &GfT) {
     const int Na = p->Na, Nb = p->Nb, NAP = p->NAP, NBP = p->NBP, KAP = p->KAP, KBP = p->KBP;
     const int nkb = Nb / 2 + 1;
     const double sa = 1.0 / std::sqrt((double)Na), sb = 1.0 / std::sqrt((double)Nb);
@@ -356,6 +379,8 @@ void build_dft(const surfh_plan *p, std::vector<float> &Fi, std::vector<float> &
     Ff.assign((size_t)2 * KAP * 2 * NAP, 0.f);
     Gi.assign((size_t)2 * KBP * NBP, 0.f);
     Gf.assign((size_t)NBP * 2 * KBP, 0.f);
+    GiT.assign((size_t)NBP * 2 * KBP, 0.f);
+    GfT.assign((size_t)2 * KBP * NBP, 0.f);
     for (int a = 0; a < Na; ++a)
         for (int k = 0; k < Na; ++k) {
             const long m = ((long)a * k) % Na;   // exact phase reduction
@@ -382,52 +407,106 @@ void build_dft(const surfh_plan *p, std::vector<float> &Fi, std::vector<float> &
             Gi[((size_t)1 * KBP + k) * NBP + b] = (float)(-w * s);
             Gf[(size_t)b * (2 * KBP) + 0 * KBP + k] = (float)c;
             Gf[(size_t)b * (2 * KBP) + 1 * KBP + k] = (float)(-s);
+            GiT[(size_t)b * (2 * KBP) + 0 * KBP + k] = (float)(w * c);
+            GiT[(size_t)b * (2 * KBP) + 1 * KBP + k] = (float)(-w * s);
+            GfT[((size_t)0 * KBP + k) * NBP + b] = (float)c;
+            GfT[((size_t)1 * KBP + k) * NBP + b] = (float)(-s);
         }
 }
 
-// ---- the two 2-D transforms as GEMM pairs ----------------------------------------------------
-// real [B][NAP][NBP] -> spec [B][2][KAP][KBP]   (tmp = ycol viewed as [B][NAP][2*KBP])
-int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B, bool maps = false) {
+// ---- plane-major 2-D transforms (only for the T abundance maps) ---------------------------------
+// real [B][NAP][NBP] -> spec [B][2][KAP][KBP]   (tmp = ycol_maps viewed as [B][NAP][2*KBP])
+int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     GemmArgs g;
     g.A0 = src; g.lda = p->NBP; g.sA = p->PLc;
     g.B0 = p->Gf; g.ldb = 2 * p->KBP; g.sB = 0;
-    g.C = p->ycol; g.ldc = 2 * p->KBP; g.sC = (long)p->NAP * 2 * p->KBP;
+    g.C = p->ycol_maps; g.ldc = 2 * p->KBP; g.sC = (long)p->NAP * 2 * p->KBP;
     g.M = p->NAP; g.N = 2 * p->KBP; g.K = p->NBP; g.batch = B;
     {
-        Prof pr(p, maps ? "gemm_dft_rows_fwd_maps" : "gemm_dft_rows_fwd");
+        Prof pr(p, "gemm_dft_rows_fwd_maps");
         LAUNCH_OK(launch_gemm_f32(p->stream, g));
     }
     GemmArgs h;
     h.A0 = p->Ff; h.lda = 2 * p->NAP; h.sA = 0;
-    h.B0 = p->ycol; h.B1 = p->ycol + p->KBP; h.ksplitB = p->NAP; h.ldb = 2 * p->KBP; h.sB = (long)p->NAP * 2 * p->KBP;
+    h.B0 = p->ycol_maps; h.B1 = p->ycol_maps + p->KBP; h.ksplitB = p->NAP; h.ldb = 2 * p->KBP;
+    h.sB = (long)p->NAP * 2 * p->KBP;
     h.C = dst; h.ldc = p->KBP; h.sC = 2 * p->PL;
     h.M = 2 * p->KAP; h.N = p->KBP; h.K = 2 * p->NAP; h.batch = B;
     {
-        Prof pr(p, maps ? "gemm_dft_cols_fwd_maps" : "gemm_dft_cols_fwd");
+        Prof pr(p, "gemm_dft_cols_fwd_maps");
         LAUNCH_OK(launch_gemm_f32(p->stream, h));
     }
     return 0;
 }
 
-// spec [B][2][KAP][KBP] -> real [B][NAP][NBP]   (tmp = ycol viewed as [B][2][NAP][KBP])
-int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B, bool maps = false) {
+// spec [B][2][KAP][KBP] -> real [B][NAP][NBP]   (tmp = ycol_maps viewed as [B][2][NAP][KBP])
+int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     GemmArgs g;
     g.A0 = p->Fi; g.lda = 2 * p->KAP; g.sA = 0;
     g.B0 = src; g.ldb = p->KBP; g.sB = 2 * p->PL;
-    g.C = p->ycol; g.ldc = p->KBP; g.sC = (long)2 * p->NAP * p->KBP;
+    g.C = p->ycol_maps; g.ldc = p->KBP; g.sC = (long)2 * p->NAP * p->KBP;
     g.M = 2 * p->NAP; g.N = p->KBP; g.K = 2 * p->KAP; g.batch = B;
     {
-        Prof pr(p, maps ? "gemm_dft_cols_inv_maps" : "gemm_dft_cols_inv");
+        Prof pr(p, "gemm_dft_cols_inv_maps");
         LAUNCH_OK(launch_gemm_f32(p->stream, g));
     }
     GemmArgs h;
-    h.A0 = p->ycol; h.A1 = p->ycol + (long)p->NAP * p->KBP; h.ksplitA = p->KBP; h.lda = p->KBP;
+    h.A0 = p->ycol_maps; h.A1 = p->ycol_maps + (long)p->NAP * p->KBP; h.ksplitA = p->KBP; h.lda = p->KBP;
     h.sA = (long)2 * p->NAP * p->KBP;
     h.B0 = p->Gi; h.ldb = p->NBP; h.sB = 0;
     h.C = dst; h.ldc = p->NBP; h.sC = p->PLc;
     h.M = p->NAP; h.N = p->NBP; h.K = 2 * p->KBP; h.batch = B;
     {
-        Prof pr(p, maps ? "gemm_dft_rows_inv_maps" : "gemm_dft_rows_inv");
+        Prof pr(p, "gemm_dft_rows_inv_maps");
+        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+    }
+    return 0;
+}
+
+// ---- wavelength-innermost 2-D transforms of the whole owned cube -------------------------------
+// cube [NBP][NAP][LP] -> spec [2][KAP][KBP][LP]        (tmp ycol viewed as Z[2][KBP][NAP][LP])
+int rfft2_lam(surfh_plan *p, const float *src, float *dst) {
+    const long LP = p->LP;
+    GemmArgs g;   // Z[(c,kb)][(a,l)] = GfT[(c,kb)][b] * cube[b][(a,l)]
+    g.A0 = p->GfT; g.lda = p->NBP;
+    g.B0 = src; g.ldb = p->NAP * LP;
+    g.C = p->ycol; g.ldc = p->NAP * LP;
+    g.M = 2 * p->KBP; g.N = (int)(p->NAP * LP); g.K = p->NBP;
+    {
+        Prof pr(p, "gemm_dft_rows_fwd");
+        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+    }
+    GemmArgs h;   // per kb: S[(c,ka)][l] = Ff[(c,ka)][(c',a)] * Z[c'][kb][a][l]
+    h.A0 = p->Ff; h.lda = 2 * p->NAP;
+    h.B0 = p->ycol; h.B1 = p->ycol + (long)p->KBP * p->NAP * LP; h.ksplitB = p->NAP; h.ldb = LP; h.sB = p->NAP * LP;
+    h.C = dst; h.ldc = p->KBP * LP; h.sC = LP;
+    h.M = 2 * p->KAP; h.N = (int)LP; h.K = 2 * p->NAP; h.batch = p->KBP;
+    {
+        Prof pr(p, "gemm_dft_cols_fwd");
+        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+    }
+    return 0;
+}
+
+// spec [2][KAP][KBP][LP] -> cube [NBP][NAP][LP]        (tmp ycol viewed as Y[2][NAP][KBP][LP])
+int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
+    const long LP = p->LP;
+    GemmArgs g;   // Y[(c,a)][(kb,l)] = Fi[(c,a)][(c',ka)] * S[(c',ka)][(kb,l)]
+    g.A0 = p->Fi; g.lda = 2 * p->KAP;
+    g.B0 = src; g.ldb = p->KBP * LP;
+    g.C = p->ycol; g.ldc = p->KBP * LP;
+    g.M = 2 * p->NAP; g.N = (int)(p->KBP * LP); g.K = 2 * p->KAP;
+    {
+        Prof pr(p, "gemm_dft_cols_inv");
+        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+    }
+    GemmArgs h;   // per a: cube[b][a][l] = GiT[b][(c,kb)] * Y[c][a][kb][l]
+    h.A0 = p->GiT; h.lda = 2 * p->KBP;
+    h.B0 = p->ycol; h.B1 = p->ycol + (long)p->NAP * p->KBP * LP; h.ksplitB = p->KBP; h.ldb = LP; h.sB = p->KBP * LP;
+    h.C = dst; h.ldc = p->NAP * LP; h.sC = LP;
+    h.M = p->NBP; h.N = (int)LP; h.K = 2 * p->KBP; h.batch = p->NAP;
+    {
+        Prof pr(p, "gemm_dft_rows_inv");
         LAUNCH_OK(launch_gemm_f32(p->stream, h));
     }
     return 0;
@@ -443,38 +522,37 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             Prof pr(p, "pad_planes");
             LAUNCH_OK(launch_pad_planes(s, x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
         }
-        if (rfft2_planes(p, p->maps_pad, p->mhat, p->T, true)) return 1;
+        if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
     } else {
         {
-            Prof pr(p, "pad_planes");
-            LAUNCH_OK(launch_pad_planes(s, x + (long)p->lo * p->Na * p->Nb, p->cube, p->Lown, p->Na, p->Nb, p->NAP, p->NBP));
+            Prof pr(p, "cube_transpose");
+            LAUNCH_OK(launch_cube_to_lam_inner(s, x, p->cube, p->lo, p->Lown, p->Na, p->Nb, p->NAP, p->LP));
         }
-        if (rfft2_planes(p, p->cube, p->mhat, p->Lown)) return 1;
+        if (rfft2_lam(p, p->cube, p->mhat)) return 1;
     }
     {
         Prof pr(p, "specmix_fwd");
-        LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->Lown, p->PL));
+        LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP));
     }
-    if (irfft2_planes(p, p->spec, p->cube, p->Lown)) return 1;
+    if (irfft2_lam(p, p->spec, p->cube)) return 1;
     for (auto &c : p->ch) {
         {
             Prof pr(p, "spmm_gather_fwd");
-            LAUNCH_OK(launch_spmm_ell(s, c.fwd.t, p->cube + (long)(c.ws0 - p->lo) * p->PLc, p->PLc, c.Xs,
-                                      (long)c.nbs * c.NP, c.Lin, 0));
+            LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0));
         }
-        GemmArgs g;
-        g.A0 = c.W; g.lda = c.KP;
-        g.B0 = c.Xs; g.ldb = c.NP;
-        g.C = c.Cpart; g.ldc = c.NP;
-        g.M = c.LdetP; g.N = c.NP; g.K = c.KP; g.splitK = c.splitK; g.sCsplit = (long)c.LdetP * c.NP;
+        GemmArgs g;   // y^T[n][l'] = Xs[n][k] Wt[k][l']
+        g.A0 = c.Xs; g.lda = c.K;
+        g.B0 = c.Wt; g.ldb = c.LdetP;
+        g.C = c.Cpart; g.ldc = c.LdetP;
+        g.M = c.NP; g.N = c.LdetP; g.K = c.K; g.splitK = c.splitK; g.sCsplit = (long)c.NP * c.LdetP;
         {
             Prof pr(p, "gemm_wblur_fwd");
             LAUNCH_OK(launch_gemm_f32(s, g));
         }
         {
             Prof pr(p, "y_from_cpart");
-            LAUNCH_OK(launch_y_from_cpart(s, c.Cpart, (long)c.LdetP * c.NP, c.splitK, y + c.yoff, c.P * c.S, c.Ldet,
-                                          c.aout, c.NP));
+            LAUNCH_OK(launch_y_from_cpart(s, c.Cpart, (long)c.NP * c.LdetP, c.splitK, y + c.yoff, c.P * c.S, c.Ldet,
+                                          c.aout, c.LdetP));
         }
     }
     return 0;
@@ -484,45 +562,44 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
     hipStream_t s = p->stream;
     {
         Prof pr(p, "fill_zero");
-        LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->Lown * p->PLc));
+        LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
     }
     for (auto &c : p->ch) {
         if (ref && !c.has_ref) return fail("adjoint_ref needs the gridding_t tables (gt_*) in the channel descriptor");
         {
             Prof pr(p, "ymat_from_y");
-            LAUNCH_OK(launch_ymat_from_y(s, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.NP));
+            LAUNCH_OK(launch_ymat_from_y(s, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP));
         }
-        GemmArgs g;
-        g.A0 = c.Wt; g.lda = c.LdetP;
-        g.B0 = c.ymat; g.ldb = c.NP;
-        g.C = c.Xs; g.ldc = c.NP;
-        g.M = c.KP; g.N = c.NP; g.K = c.LdetP;
+        GemmArgs g;   // Xs_t[n][k] = y^T[n][l'] W[l'][k]
+        g.A0 = c.ymat; g.lda = c.LdetP;
+        g.B0 = c.W; g.ldb = c.K;
+        g.C = c.Xs; g.ldc = c.K;
+        g.M = c.NP; g.N = c.K; g.K = c.LdetP;
         {
             Prof pr(p, "gemm_wblur_adj");
             LAUNCH_OK(launch_gemm_f32(s, g));
         }
         {
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
-            LAUNCH_OK(launch_spmm_ell(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, (long)c.nbs * c.NP,
-                                      p->cube + (long)(c.ws0 - p->lo) * p->PLc, p->PLc, c.Lin, 1));
+            LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
         }
     }
-    if (rfft2_planes(p, p->cube, p->spec, p->Lown)) return 1;
+    if (rfft2_lam(p, p->cube, p->spec)) return 1;
     {
         Prof pr(p, "specmix_adj");
-        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->partial, p->mhat, p->T, p->Lown, p->PL, p->nchunk));
+        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP));
     }
     if (p->T > 0) {
-        if (irfft2_planes(p, p->mhat, p->maps_pad, p->T, true)) return 1;
+        if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
         Prof pr(p, "unpad_planes");
         LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     } else {
-        if (irfft2_planes(p, p->mhat, p->cube, p->Lown)) return 1;
+        if (irfft2_lam(p, p->mhat, p->cube)) return 1;
         const long pl = (long)p->Na * p->Nb;
         if (p->lo > 0) LAUNCH_OK(launch_fill_zero(s, x, (long)p->lo * pl));
         if (p->hi < p->Lc) LAUNCH_OK(launch_fill_zero(s, x + (long)p->hi * pl, (long)(p->Lc - p->hi) * pl));
-        Prof pr(p, "unpad_planes");
-        LAUNCH_OK(launch_unpad_planes(s, p->cube, x + (long)p->lo * pl, p->Lown, p->Na, p->Nb, p->NAP, p->NBP));
+        Prof pr(p, "cube_transpose");
+        LAUNCH_OK(launch_cube_from_lam_inner(s, p->cube, x, p->lo, p->Lown, p->Na, p->Nb, p->NAP, p->LP));
     }
     return 0;
 }
@@ -558,8 +635,8 @@ int surfh_plan_destroy(surfh_plan *p) {
     if (!p) return 0;
     hipSetDevice(p->dev);
     if (p->stream) hipStreamSynchronize(p->stream);
-    for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->partial, p->maps_pad, p->Fi, p->Gi, p->Gf,
-                     p->Ff, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
+    for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
+                     p->Ff, p->GiT, p->GfT, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
         hipFree(v);
     hipFree(p->dscal);
     hipFree(p->dscratch);
@@ -621,52 +698,60 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     }
     if (p->lo < 0 || p->hi > p->Lc || p->lo >= p->hi) return bail(fail("channel wslices outside the cube"));
     p->Lown = p->hi - p->lo;
-    p->nplanes_m = p->T > 0 ? p->T : p->Lown;
+    p->LP = (p->Lown + 127) / 128 * 128;
     p->isize = (long)(p->T > 0 ? p->T : p->Lc) * p->Na * p->Nb;
-    p->nchunk = std::max(1, std::min(32, p->Lown / 16));
+    const size_t LP = (size_t)p->LP;
 
     // ---- constants ------------------------------------------------------------------------
-    {
+    {   // sotf [Lc][Na][Nb/2+1] complex128  ->  [2][KAP][KBP][LP] float, wavelength innermost
         const int nkb = p->Nb / 2 + 1;
-        if (dev_alloc(&p->sotf, (size_t)p->Lown * 2 * p->PL)) return bail(1);
-        std::vector<float> plane((size_t)2 * p->PL);
-        for (int l = 0; l < p->Lown; ++l) {
-            std::fill(plane.begin(), plane.end(), 0.f);
-            const double *src = cfg->sotf + (size_t)(p->lo + l) * p->Na * nkb * 2;
-            for (int a = 0; a < p->Na; ++a)
+        const size_t nsp = (size_t)2 * p->PL * LP;
+        if (dev_alloc(&p->sotf, nsp)) return bail(1);
+        if (hipMemset(p->sotf, 0, nsp * sizeof(float)) != hipSuccess) return bail(fail("memset failed"));
+        std::vector<float> row((size_t)2 * p->KBP * LP);
+        for (int a = 0; a < p->Na; ++a) {
+            std::fill(row.begin(), row.end(), 0.f);
+            for (int l = 0; l < p->Lown; ++l) {
+                const double *src = cfg->sotf + ((size_t)(p->lo + l) * p->Na + a) * nkb * 2;
                 for (int k = 0; k < nkb; ++k) {
-                    plane[(size_t)a * p->KBP + k] = (float)src[((size_t)a * nkb + k) * 2 + 0];
-                    plane[(size_t)p->PL + (size_t)a * p->KBP + k] = (float)src[((size_t)a * nkb + k) * 2 + 1];
+                    row[(size_t)k * LP + l] = (float)src[2 * k];
+                    row[((size_t)p->KBP + k) * LP + l] = (float)src[2 * k + 1];
                 }
-            if (hipMemcpy(p->sotf + (size_t)l * 2 * p->PL, plane.data(), plane.size() * sizeof(float),
-                          hipMemcpyHostToDevice) != hipSuccess)
-                return bail(fail("sotf upload failed"));
+            }
+            for (int c = 0; c < 2; ++c)
+                if (hipMemcpy(p->sotf + ((size_t)c * p->PL + (size_t)a * p->KBP) * LP, row.data() + (size_t)c * p->KBP * LP,
+                              (size_t)p->KBP * LP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(fail("sotf upload failed"));
         }
     }
     if (p->T > 0) {
-        std::vector<float> t((size_t)p->T * p->Lown);
+        std::vector<float> t((size_t)p->T * LP, 0.f);
         for (int k = 0; k < p->T; ++k)
-            for (int l = 0; l < p->Lown; ++l) t[(size_t)k * p->Lown + l] = (float)cfg->templates[(size_t)k * p->Lc + p->lo + l];
+            for (int l = 0; l < p->Lown; ++l) t[(size_t)k * LP + l] = (float)cfg->templates[(size_t)k * p->Lc + p->lo + l];
         if (dev_upload(&p->tpl, t)) return bail(1);
     }
     {
-        std::vector<float> Fi, Gi, Gf, Ff;
-        build_dft(p, Fi, Gi, Gf, Ff);
-        if (dev_upload(&p->Fi, Fi) || dev_upload(&p->Gi, Gi) || dev_upload(&p->Gf, Gf) || dev_upload(&p->Ff, Ff)) return bail(1);
+        std::vector<float> Fi, Gi, Gf, Ff, GiT, GfT;
+        build_dft(p, Fi, Gi, Gf, Ff, GiT, GfT);
+        if (dev_upload(&p->Fi, Fi) || dev_upload(&p->Gi, Gi) || dev_upload(&p->Gf, Gf) || dev_upload(&p->Ff, Ff) ||
+            dev_upload(&p->GiT, GiT) || dev_upload(&p->GfT, GfT))
+            return bail(1);
     }
     // ---- work buffers ---------------------------------------------------------------------
-    const size_t nspec = (size_t)p->Lown * 2 * p->PL, ncube = (size_t)p->Lown * p->PLc;
-    const size_t nycol = (size_t)std::max(p->Lown, p->nplanes_m) * 2 * p->NAP * p->KBP;
+    const size_t nspec = (size_t)2 * p->PL * LP, ncube = (size_t)p->NBP * p->NAP * LP;
+    const size_t nycol = (size_t)2 * p->NAP * p->KBP * LP;
+    const size_t nmhat = p->T > 0 ? (size_t)p->T * 2 * p->PL : nspec;
+    const size_t nmaps = (size_t)std::max(p->T, 1) * p->PLc;
+    const size_t nycm = (size_t)std::max(p->T, 1) * 2 * p->NAP * p->KBP;
     if (dev_alloc(&p->spec, nspec) || dev_alloc(&p->ycol, nycol) || dev_alloc(&p->cube, ncube) ||
-        dev_alloc(&p->mhat, (size_t)p->nplanes_m * 2 * p->PL) ||
-        dev_alloc(&p->maps_pad, (size_t)std::max(p->T, 1) * p->PLc) ||
-        dev_alloc(&p->partial, (size_t)p->nchunk * std::max(p->T, 1) * 2 * p->PL))
+        dev_alloc(&p->mhat, nmhat) || dev_alloc(&p->maps_pad, nmaps) || dev_alloc(&p->ycol_maps, nycm))
         return bail(1);
     hipMemset(p->spec, 0, nspec * sizeof(float));
     hipMemset(p->ycol, 0, nycol * sizeof(float));
     hipMemset(p->cube, 0, ncube * sizeof(float));
-    hipMemset(p->mhat, 0, (size_t)p->nplanes_m * 2 * p->PL * sizeof(float));
-    hipMemset(p->maps_pad, 0, (size_t)std::max(p->T, 1) * p->PLc * sizeof(float));
+    hipMemset(p->mhat, 0, nmhat * sizeof(float));
+    hipMemset(p->maps_pad, 0, nmaps * sizeof(float));
+    hipMemset(p->ycol_maps, 0, nycm * sizeof(float));
     // ---- channels -------------------------------------------------------------------------
     p->ch.resize(cfg->n_channels);
     long yoff = 0;
@@ -677,6 +762,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         yoff += c.ysize;
         c.splitK = pick_split(c, cfg->split_k_forward);
         if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
+        hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));
     }
     p->osize = yoff;
     if (dev_alloc(&p->io_x, (size_t)p->isize) || dev_alloc(&p->io_y, (size_t)p->osize) || dev_alloc(&p->cg_y, (size_t)p->osize) ||
@@ -877,18 +963,24 @@ int surfh_profile_reset(surfh_plan *p) {
 static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t dims[4]) {
     std::string w(which ? which : "");
     dims[0] = dims[1] = dims[2] = dims[3] = 1;
-    if (w == "blurred" || w == "gcube") {
-        *ptr = p->cube; dims[0] = p->Lown; dims[1] = p->NAP; dims[2] = p->NBP;
-    } else if (w == "spec") {
-        *ptr = p->spec; dims[0] = p->Lown; dims[1] = 2; dims[2] = p->KAP; dims[3] = p->KBP;
-    } else if (w == "mhat") {
-        *ptr = p->mhat; dims[0] = p->nplanes_m; dims[1] = 2; dims[2] = p->KAP; dims[3] = p->KBP;
-    } else if (w.rfind("xs:", 0) == 0) {
-        const int c = atoi(w.c_str() + 3);
+    *ptr = nullptr;
+    if (w == "blurred" || w == "gcube") {          // [beta][alpha][lambda]
+        *ptr = p->cube; dims[0] = p->NBP; dims[1] = p->NAP; dims[2] = p->LP;
+    } else if (w == "spec") {                       // [2][k_alpha][k_beta][lambda]
+        *ptr = p->spec; dims[0] = 2; dims[1] = p->KAP; dims[2] = p->KBP; dims[3] = p->LP;
+    } else if (w == "mhat" && p->T > 0) {
+        *ptr = p->mhat; dims[0] = p->T; dims[1] = 2; dims[2] = p->KAP; dims[3] = p->KBP;
+    } else if (w.rfind("xs:", 0) == 0 || w.rfind("xsinfo:", 0) == 0) {
+        const bool info = w[2] == 'i';
+        const int c = atoi(w.c_str() + (info ? 7 : 3));
         if (c < 0 || c >= (int)p->ch.size()) return fail("bad channel index");
-        *ptr = p->ch[c].Xs; dims[0] = p->ch[c].KP; dims[1] = p->ch[c].NP;
+        if (info) {                                 // (LinP, first valid lambda column, n_beta_slit, Lin)
+            dims[0] = p->ch[c].LinP; dims[1] = p->ch[c].shift; dims[2] = p->ch[c].nbs; dims[3] = p->ch[c].Lin;
+        } else {                                    // [(p,s,a)][b'][LinP]
+            *ptr = p->ch[c].Xs; dims[0] = p->ch[c].NP; dims[1] = p->ch[c].nbs; dims[2] = p->ch[c].LinP;
+        }
     } else if (w == "info") {
-        *ptr = nullptr; dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->ch.empty() ? 0 : p->ch[0].splitK; dims[3] = p->ch.empty() ? 0 : p->ch[0].adjT.t.W;
+        dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->ch.empty() ? 0 : p->ch[0].splitK; dims[3] = p->ch.empty() ? 0 : p->ch[0].adjT.t.W;
     } else {
         return fail("unknown debug buffer '%s'", w.c_str());
     }

@@ -75,8 +75,8 @@ def test_stage_blurred_cube(c1):
     cfg, om, m = c1
     m.forward(cfg["maps"])
     N = cfg["N"]
-    b = m.debug_buffer("blurred")[:, :N, :N]
     lo, hi = int(m.debug_buffer("info")[0]), int(m.debug_buffer("info")[1])
+    b = m.debug_buffer("blurred").transpose(2, 1, 0)[: hi - lo, :N, :N]     # device layout is [beta][alpha][lambda]
     ref = om.blur(cfg["maps"])[lo:hi]
     e = rel(b, ref)
     note("blurred", err=e)
@@ -90,8 +90,11 @@ def test_stage_gemm_operand(c1):
     cfg, om, m = c1
     m.forward(cfg["maps"])
     tab = om.channels[0]
-    ref = oracle_xs(om, tab, om.blur(cfg["maps"]))
-    xs = m.debug_buffer("xs:0")[: ref.shape[0], : ref.shape[1]]
+    ref = oracle_xs(om, tab, om.blur(cfg["maps"]))                     # [(l,b'), (p,s,a)]
+    LinP, shift, nbs, Lin = (int(v) for v in m.debug_buffer("xsinfo:0"))
+    xs = m.debug_buffer("xs:0")                                         # device layout [(p,s,a)][b'][LinP]
+    ref = ref.reshape(Lin, nbs, -1).transpose(2, 1, 0)
+    xs = xs[: ref.shape[0], :, shift: shift + Lin]
     e = rel(xs, ref)
     note("xs", err=e)
     assert e < TOL
@@ -141,6 +144,13 @@ def test_dottest(c1):
     # (DESIGN.md "Precision"); the median meets the < 1e-6 target, every draw meets aljabr's rtol=1e-5.
     assert np.median(gaps) < 1e-6 and max(gaps) < 1e-5
     assert dottest(m, num=2, rng=rng)
+    pg = []
+    for _ in range(3):       # non-negative test vectors: no cancellation in <u, A v>, strict < 1e-6
+        v, u = rng.random(m.isize), rng.random(m.osize)
+        l = float(np.vdot(m.rmatvec(u), v)); r = float(np.vdot(u, m.matvec(v)))
+        pg.append(abs(l - r) / abs(r))
+    note("dottest_uniform", gaps=[float(x) for x in pg])
+    assert max(pg) < 1e-6
 
 
 def test_fwadj_and_linearity(c1):
