@@ -109,7 +109,7 @@ def main():
         fus.step()
 
     def fence():
-        fus.tstream.synchronize()
+        fus._sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -140,7 +140,7 @@ def main():
         Lown = int(info[1] - info[0])
         groups = {}
         for name, (cnt, ms) in prof.items():
-            g = "gemm_dft" if name.startswith("gemm_dft_") and not name.endswith("_maps") else \
+            g = "dft_pass" if (name.startswith("gemm_dft_") and not name.endswith("_maps")) or name.startswith("dft_fold_") else \
                 "gemm_wblur" if name.startswith("gemm_wblur") else name
             a = groups.setdefault(g, [0, 0.0])
             a[0] += cnt
@@ -159,13 +159,15 @@ def main():
                         "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "gemm_f32_kernel (R / R^T)",
                         "launches": cnt, "avg_ms": ms / cnt}
             else:
-                # FFT-conv stage: one 2-D transform pass over the owned planes algorithmically moves
-                # Lown*(Nf*8 + N^2*4) bytes; each pass is two 1-D launches of this kernel.
-                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4)
+                # FFT-conv stage: one 2-D transform over the owned planes algorithmically moves
+                # Lown*(Nf*8 + N^2*4) bytes; a CG step holds two such transforms (one per
+                # direction), each made of cnt/steps/2 launches of this kernel.
+                per_step = cnt / max(1, args.steps)
+                bytes_launch = 2.0 * Lown * (Nf * 8 + N * N * 4) / per_step if dom == "dft_pass" else 0.0
                 ach = bytes_launch / (ms / cnt * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": f"{dom} (gemm_f32_kernel as 1-D DFT pass over {Lown} planes)" if dom == "gemm_dft" else dom,
+                        "kernel": f"{dom} (1-D DFT passes of the FFT-conv stage over {Lown} planes)" if dom == "dft_pass" else dom,
                         "launches": cnt, "avg_ms": ms / cnt}
         out = {
             "metric": "CG-iterations/sec (forward+adjoint) on 251x251x4000 cube" if args.config == "3"

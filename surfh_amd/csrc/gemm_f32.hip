@@ -141,7 +141,9 @@ int launch_gemm_f32(hipStream_t stream, const GemmArgs &g) {
     if (g.ksplitB != (1 << 30) && g.ksplitB % BK) return (int)hipErrorInvalidValue;
     if (g.splitK > 1 && g.accumulate) return (int)hipErrorInvalidValue;
     // K slabs must not straddle a ksplit boundary inside a K tile: guaranteed by the %BK checks above
-    const bool m128 = (g.M % 128 == 0), n128 = (g.N % 128 == 0);
+    bool m128 = (g.M % 128 == 0), n128 = (g.N % 128 == 0);
+    // small problems (the T abundance-map transforms): prefer 64-wide tiles so the launch fills more CUs
+    if ((long)(g.M / 128 + 1) * (g.N / 128 + 1) * g.batch * g.splitK < 256) m128 = n128 = false;
     const int bm = m128 ? 128 : 64, bn = n128 ? 128 : 64;
     dim3 grid((g.M / bm) * (g.N / bn), 1, g.batch * g.splitK), block(256);
     if (m128 && n128)

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/surfh_amd.h"
+#include "dft_fold.h"
 #include "gemm_f32.h"
 #include "kernels.h"
 
@@ -99,6 +100,10 @@ struct surfh_plan {
     float *sotf = nullptr, *tpl = nullptr, *mhat = nullptr, *spec = nullptr, *ycol = nullptr, *cube = nullptr,
           *maps_pad = nullptr, *ycol_maps = nullptr;
     float *Fi = nullptr, *Gi = nullptr, *Gf = nullptr, *Ff = nullptr, *GiT = nullptr, *GfT = nullptr;
+    // folded-DFT matrices [MPx][KPx]: cos/sin along alpha; weighted cos/sin for c2r; plain cos/sin for r2c
+    float *Cma = nullptr, *Sma = nullptr, *Gc = nullptr, *Gs = nullptr, *Cf = nullptr, *Sf = nullptr;
+    int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
+    bool dense_dft = false;
     float *io_x = nullptr, *io_y = nullptr;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
@@ -512,9 +517,71 @@ int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
     return 0;
 }
 
+// ---- the same two transforms with the symmetry-folded kernel (dft_fold.h): 3x fewer flops --------
+int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
+    const long LP = p->LP;
+    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    DftFoldArgs g;   // r2c along beta: Zr[kb] = Cf * fold+(cube), Zi[kb] = -Sf * fold-(cube)
+    g.A[0] = p->Cf; g.A[1] = p->Sf; g.lda = p->KPb;
+    g.src[0] = src; g.src[1] = src; g.ldb = p->NAP * LP; g.fold[0] = 1.f; g.fold[1] = -1.f; g.Kn = p->Nb;
+    g.dst[0] = p->ycol; g.dst[1] = p->ycol + (long)p->KBP * p->NAP * LP; g.ldc = p->NAP * LP;
+    g.mode = 1; g.e00 = 1.f; g.e11 = -1.f; g.rvalid = hb;
+    g.MP = p->MPb; g.KP = p->KPb; g.N = (int)(p->Na * LP);
+    {
+        Prof pr(p, "dft_fold_rows_fwd");
+        LAUNCH_OK(launch_dft_fold(p->stream, g));
+    }
+    for (int z = 0; z < 2; ++z) {   // c2c along alpha, one launch per output component, batched over k_beta
+        DftFoldArgs h;
+        h.A[0] = z ? p->Sma : p->Cma; h.A[1] = z ? p->Cma : p->Sma; h.lda = p->KPa;
+        h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->KBP * p->NAP * LP; h.ldb = LP; h.sB = p->NAP * LP;
+        h.fold[0] = z ? -1.f : 1.f; h.fold[1] = z ? 1.f : -1.f; h.Kn = p->Na;
+        h.dst[0] = dst + (long)z * p->PL * LP; h.ldc = p->KBP * LP; h.sC = LP;
+        h.mode = 0; h.Rn = p->Na; h.rvalid = ha;
+        if (z == 0) { h.e00 = 1.f; h.e01 = 1.f; h.e10 = 1.f; h.e11 = -1.f; }
+        else        { h.e00 = -1.f; h.e01 = 1.f; h.e10 = 1.f; h.e11 = 1.f; }
+        h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
+        Prof pr(p, "dft_fold_cols_fwd");
+        LAUNCH_OK(launch_dft_fold(p->stream, h));
+    }
+    return 0;
+}
+
+int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
+    const long LP = p->LP;
+    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    for (int z = 0; z < 2; ++z) {   // c2c along alpha
+        DftFoldArgs g;
+        g.A[0] = z ? p->Sma : p->Cma; g.A[1] = z ? p->Cma : p->Sma; g.lda = p->KPa;
+        g.src[0] = src; g.src[1] = src + p->PL * LP; g.ldb = p->KBP * LP;
+        g.fold[0] = z ? -1.f : 1.f; g.fold[1] = z ? 1.f : -1.f; g.Kn = p->Na;
+        g.dst[0] = p->ycol + (long)z * p->NAP * p->KBP * LP; g.ldc = p->KBP * LP;
+        g.mode = 0; g.Rn = p->Na; g.rvalid = ha;
+        if (z == 0) { g.e00 = 1.f; g.e01 = -1.f; g.e10 = 1.f; g.e11 = 1.f; }
+        else        { g.e00 = 1.f; g.e01 = 1.f; g.e10 = -1.f; g.e11 = 1.f; }
+        g.MP = p->MPa; g.KP = p->KPa; g.N = (int)(hb * LP);
+        Prof pr(p, "dft_fold_cols_inv");
+        LAUNCH_OK(launch_dft_fold(p->stream, g));
+    }
+    DftFoldArgs h;   // c2r along beta, batched over alpha: cube[b] = Gc*Yr - Gs*Yi, cube[N-b] = Gc*Yr + Gs*Yi
+    h.A[0] = p->Gc; h.A[1] = p->Gs; h.lda = p->KPb;
+    h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->NAP * p->KBP * LP; h.ldb = LP; h.sB = p->KBP * LP;
+    h.dst[0] = dst; h.ldc = p->NAP * LP; h.sC = LP;
+    h.mode = 0; h.e00 = 1.f; h.e01 = -1.f; h.e10 = 1.f; h.e11 = 1.f; h.Rn = p->Nb; h.rvalid = hb;
+    h.MP = p->MPb; h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
+    {
+        Prof pr(p, "dft_fold_rows_inv");
+        LAUNCH_OK(launch_dft_fold(p->stream, h));
+    }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // pipelines on device buffers
 // ---------------------------------------------------------------------------------------------
+int rfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? rfft2_lam(p, src, dst) : rfft2_lam_fold(p, src, dst); }
+int irfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_fold(p, src, dst); }
+
 int forward_dev(surfh_plan *p, const float *x, float *y) {
     hipStream_t s = p->stream;
     if (p->T > 0) {
@@ -528,13 +595,13 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             Prof pr(p, "cube_transpose");
             LAUNCH_OK(launch_cube_to_lam_inner(s, x, p->cube, p->lo, p->Lown, p->Na, p->Nb, p->NAP, p->LP));
         }
-        if (rfft2_lam(p, p->cube, p->mhat)) return 1;
+        if (rfft2_cube(p, p->cube, p->mhat)) return 1;
     }
     {
         Prof pr(p, "specmix_fwd");
         LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP));
     }
-    if (irfft2_lam(p, p->spec, p->cube)) return 1;
+    if (irfft2_cube(p, p->spec, p->cube)) return 1;
     for (auto &c : p->ch) {
         {
             Prof pr(p, "spmm_gather_fwd");
@@ -584,7 +651,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
         }
     }
-    if (rfft2_lam(p, p->cube, p->spec)) return 1;
+    if (rfft2_cube(p, p->cube, p->spec)) return 1;
     {
         Prof pr(p, "specmix_adj");
         LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP));
@@ -594,7 +661,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
         Prof pr(p, "unpad_planes");
         LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     } else {
-        if (irfft2_lam(p, p->mhat, p->cube)) return 1;
+        if (irfft2_cube(p, p->mhat, p->cube)) return 1;
         const long pl = (long)p->Na * p->Nb;
         if (p->lo > 0) LAUNCH_OK(launch_fill_zero(s, x, (long)p->lo * pl));
         if (p->hi < p->Lc) LAUNCH_OK(launch_fill_zero(s, x + (long)p->hi * pl, (long)(p->Lc - p->hi) * pl));
@@ -636,7 +703,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipSetDevice(p->dev);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
-                     p->Ff, p->GiT, p->GfT, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
+                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
         hipFree(v);
     hipFree(p->dscal);
     hipFree(p->dscratch);
@@ -735,6 +802,35 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         build_dft(p, Fi, Gi, Gf, Ff, GiT, GfT);
         if (dev_upload(&p->Fi, Fi) || dev_upload(&p->Gi, Gi) || dev_upload(&p->Gf, Gf) || dev_upload(&p->Ff, Ff) ||
             dev_upload(&p->GiT, GiT) || dev_upload(&p->GfT, GfT))
+            return bail(1);
+    }
+    {   // folded-DFT matrices
+        const char *e = getenv("SURFH_DFT_DENSE");
+        p->dense_dft = e && e[0] == '1';
+        const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+        p->MPa = (ha + 127) / 128 * 128; p->KPa = (ha + 15) / 16 * 16;
+        p->MPb = (hb + 127) / 128 * 128; p->KPb = (hb + 15) / 16 * 16;
+        if (p->KPa > p->NAP || p->KPb > p->NBP || p->KPb > p->KBP) return bail(fail("cube too small for the folded DFT"));
+        const double sa = 1.0 / std::sqrt((double)p->Na), sb = 1.0 / std::sqrt((double)p->Nb);
+        std::vector<float> Cma((size_t)p->MPa * p->KPa, 0.f), Sma(Cma.size(), 0.f);
+        for (int r = 0; r < ha; ++r)
+            for (int k = 0; k < ha; ++k) {
+                const double th = 2.0 * M_PI * (double)(((long)r * k) % p->Na) / (double)p->Na;
+                Cma[(size_t)r * p->KPa + k] = (float)(std::cos(th) * sa);
+                Sma[(size_t)r * p->KPa + k] = (float)(std::sin(th) * sa);
+            }
+        std::vector<float> Gc((size_t)p->MPb * p->KPb, 0.f), Gs(Gc.size(), 0.f), Cf(Gc.size(), 0.f), Sf(Gc.size(), 0.f);
+        for (int b = 0; b < hb; ++b)
+            for (int k = 0; k < hb; ++k) {
+                const double th = 2.0 * M_PI * (double)(((long)b * k) % p->Nb) / (double)p->Nb;
+                const double w = (k == 0 || (p->Nb % 2 == 0 && k == p->Nb / 2)) ? 1.0 : 2.0;
+                Gc[(size_t)b * p->KPb + k] = (float)(w * std::cos(th) * sb);     // rows beta, cols k_beta
+                Gs[(size_t)b * p->KPb + k] = (float)(w * std::sin(th) * sb);
+                Cf[(size_t)k * p->KPb + b] = (float)(std::cos(th) * sb);         // rows k_beta, cols beta
+                Sf[(size_t)k * p->KPb + b] = (float)(std::sin(th) * sb);
+            }
+        if (dev_upload(&p->Cma, Cma) || dev_upload(&p->Sma, Sma) || dev_upload(&p->Gc, Gc) || dev_upload(&p->Gs, Gs) ||
+            dev_upload(&p->Cf, Cf) || dev_upload(&p->Sf, Sf))
             return bail(1);
     }
     // ---- work buffers ---------------------------------------------------------------------

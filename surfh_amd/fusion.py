@@ -116,7 +116,11 @@ def partition_units(costs: Sequence[float], n_pointings: Sequence[int], world: i
 class DistributedFusion:
     """One rank of the channel-sharded CG.  ``prob`` is a dict as produced by ``surfh_amd.synth.problem``."""
 
-    def __init__(self, prob: dict, rank: int = 0, world: int = 1, device: int = 0, with_ref: bool = False):
+    def __init__(self, prob: dict, rank: int = 0, world: int = 1, device: int = 0, with_ref: bool = False,
+                 model_factory=None):
+        """``model_factory(ifus, pointings)`` replaces the HIP operator (used by the world_size-2 gloo
+        tests on CPU, where a checker-backed stand-in exposes the same ``*_dev`` methods on CPU tensors)."""
+        import contextlib
         import torch
         self.torch = torch
         self.rank, self.world, self.device = rank, world, device
@@ -130,13 +134,23 @@ class DistributedFusion:
         self.costs = [band_cost(n_pix, g) for g in geos]
         self.assignment = partition_units(self.costs, [len(p) for p in pts], world)
         self.units = self.assignment[rank]
-        torch.cuda.set_device(device)
-        self.tstream = torch.cuda.Stream(device=device)
         my_ifus = [ifus[k] for k, _ in self.units]
         my_pts = [instru.CoordList([pts[k][i] for i in sel]) for k, sel in self.units]
-        self.model = spectroSigRLSCT(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"],
-                                     prob["wavel"], my_ifus, prob["step_deg"], my_pts, device=device,
-                                     with_ref=with_ref, stream=self.tstream.cuda_stream)
+        if model_factory is None:
+            torch.cuda.set_device(device)
+            self.tstream = torch.cuda.Stream(device=device)
+            self.dev = f"cuda:{device}"
+            self._ctx = lambda: torch.cuda.stream(self.tstream)
+            self._sync = self.tstream.synchronize
+            self.model = spectroSigRLSCT(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"],
+                                         prob["wavel"], my_ifus, prob["step_deg"], my_pts, device=device,
+                                         with_ref=with_ref, stream=self.tstream.cuda_stream)
+        else:
+            self.tstream = None
+            self.dev = "cpu"
+            self._ctx = contextlib.nullcontext
+            self._sync = lambda: None
+            self.model = model_factory(my_ifus, my_pts)
         self.n = self.model.isize
 
     def _allreduce(self, t):
@@ -146,13 +160,14 @@ class DistributedFusion:
     def make_data(self, maps, noise_rel=1e-2, seed=1):
         """y_r = A_r maps + N(0, sigma^2), sigma = noise_rel * rms(y_r)."""
         torch = self.torch
-        with torch.cuda.stream(self.tstream):
-            x = torch.as_tensor(np.ascontiguousarray(maps, dtype=np.float32), device=f"cuda:{self.device}")
+        with self._ctx():
+            x = torch.as_tensor(np.ascontiguousarray(maps, dtype=np.float32), device=self.dev)
             y = torch.empty(self.model.osize, dtype=torch.float32, device=x.device)
             self.model.forward_dev(x, y)
-            g = torch.Generator(device=x.device).manual_seed(seed + self.rank)
-            y += torch.randn(y.shape, generator=g, device=x.device, dtype=torch.float32) * (noise_rel * y.square().mean().sqrt())
-        self.tstream.synchronize()
+            if noise_rel:
+                g = torch.Generator(device=x.device).manual_seed(seed + self.rank)
+                y += torch.randn(y.shape, generator=g, device=x.device, dtype=torch.float32) * (noise_rel * y.square().mean().sqrt())
+        self._sync()
         return y
 
     def normal(self, d, q, mu, mu_reg):
@@ -164,8 +179,8 @@ class DistributedFusion:
 
     def start(self, y, mu=1.0, mu_reg=0.0, x0=None):
         torch, m = self.torch, self.model
-        dev = f"cuda:{self.device}"
-        with torch.cuda.stream(self.tstream):
+        dev = self.dev
+        with self._ctx():
             shape = m.ishape
             self.x = torch.zeros(shape, dtype=torch.float32, device=dev) if x0 is None else \
                 torch.as_tensor(np.ascontiguousarray(x0, dtype=np.float32), device=dev).clone()
@@ -186,7 +201,7 @@ class DistributedFusion:
     def step(self, refresh=50):
         """One CG iteration (qmm.lcg loop body; oracle/surfh_oracle.py:lcg documents the recurrences)."""
         torch, m = self.torch, self.model
-        with torch.cuda.stream(self.tstream):
+        with self._ctx():
             self.normal(self.d, self.q, self.mu, self.mu_reg)
             rr_new = m.cg_step_dev(self.x, self.r, self.d, self.q, self.n, self.rr)
             if refresh and self.it % refresh == 0:
@@ -205,6 +220,6 @@ class DistributedFusion:
             rr = self.step(refresh)
             if np.sqrt(rr) < self.n * tol:
                 break
-        self.tstream.synchronize()
+        self._sync()
         return OptimizeResult(x=self.x.cpu().numpy().astype(np.float64), grad_norm=list(self.grad_norm), nit=self.it,
                               success=bool(np.sqrt(self.rr) < self.n * tol))

@@ -1,0 +1,99 @@
+"""One rank of the world_size-2 gloo rehearsal of the multi-GPU CG driver (CPU only).
+
+The HIP operator is replaced by a checker-backed stand-in with the same ``*_dev`` methods, so
+what is exercised is the product's distributed logic: unit partition, replicated vectors, the one
+all-reduce per iteration and the CG recurrences (surfh_amd/fusion.py)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from oracle import surfh_oracle as orc  # noqa: E402
+from surfh_amd import instru, synth  # noqa: E402
+from surfh_amd.fusion import DistributedFusion  # noqa: E402
+
+
+class OracleBackedModel:
+    """CPU stand-in exposing the device-pointer API of spectroSigRLSCT on CPU torch tensors."""
+
+    def __init__(self, prob, ifus, pts):
+        specs = [orc.ChannelSpec(i.fov.alpha_width, i.fov.beta_width, (i.fov.origin.alpha, i.fov.origin.beta), i.fov.angle,
+                                 i.det_pix_size, i.n_slit, i.w_blur.grating_resolution, i.wavel_axis, i.name) for i in ifus]
+        p = [[(c.alpha, c.beta) for c in pl] for pl in pts]
+        self.om = orc.OracleModel(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"], prob["wavel"],
+                                  specs, prob["step_deg"], p, box="direct")
+        self.ishape, self.isize, self.osize = self.om.ishape, self.om.isize, self.om.osize
+
+    @staticmethod
+    def _np(t):
+        return t.detach().numpy().astype(np.float64)
+
+    def forward_dev(self, x, y):
+        y.copy_(torch.from_numpy(self.om.forward(self._np(x)).astype(np.float32)))
+
+    def adjoint_dev(self, y, x):
+        x.copy_(torch.from_numpy(self.om.adjoint(self._np(y)).astype(np.float32)))
+
+    def normal_dev(self, d, q, mu):
+        q.copy_(torch.from_numpy((mu * self.om.adjoint(self.om.forward(self._np(d)))).astype(np.float32)))
+
+    def prior_add_dev(self, d, q, mu_reg):
+        x = self._np(d)
+        q += torch.from_numpy((mu_reg * (orc.diff_r_t(orc.diff_r(x)) + orc.diff_c_t(orc.diff_c(x)))).astype(np.float32))
+
+    def dot_dev(self, a, b, n):
+        return float(np.vdot(self._np(a), self._np(b)))
+
+    def cg_step_dev(self, x, r, d, q, n, rr):
+        step = rr / self.dot_dev(d, q, n)
+        x += step * d
+        r -= step * q
+        return self.dot_dev(r, r, n)
+
+    def cg_dir_dev(self, d, r, n, beta):
+        d.mul_(beta).add_(r)
+
+    def residual_dev(self, r, b, q, n):
+        r.copy_(b - q)
+
+
+def small_problem():
+    n_pix, lc = 48, 96
+    wav = np.linspace(7.40, 7.90, lc)
+    ax = synth.axes(n_pix)
+    mk = lambda fa, fb, ang, ns, R, w, name: instru.IFU(  # noqa: E731
+        fov=instru.FOV(fa / 3600, fb / 3600, origin=instru.Coord(0, 0), angle=ang), det_pix_size=0.196, n_slit=ns,
+        w_blur=instru.SpectralBlur(R), pce=None, wavel_axis=w, name=name)
+    ifus = [mk(0.6, 0.7, 8.2, 3, 3050.0, np.linspace(7.50, 7.64, 40), "A"),
+            mk(0.7, 0.6, -5.0, 2, 2900.0, np.linspace(7.60, 7.80, 36), "B")]
+    return dict(alpha_axis=ax, beta_axis=ax.copy(), wavel=wav, ifus=ifus, pointings=[synth.dither4(i) for i in ifus],
+                templates=synth.templates(lc), sotf=synth.ir2fr(synth.gaussian_psf(wav, synth.STEP), (n_pix, n_pix)),
+                step_deg=synth.STEP_DEG, maps=np.random.default_rng(7).random((4, n_pix, n_pix)))
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = small_problem()
+    fus = DistributedFusion(prob, rank=rank, world=world, model_factory=lambda i, p: OracleBackedModel(prob, i, p))
+    y = fus.make_data(prob["maps"], noise_rel=0.0)
+    res = fus.lcg(y, mu=1.0, mu_reg=50.0, max_iter=6, tol=1e-14)
+    # every rank must hold the same replicated iterate
+    xs = [torch.zeros_like(fus.x) for _ in range(world)]
+    dist.all_gather(xs, fus.x)
+    same = all(torch.equal(xs[0], t) for t in xs)
+    if rank == 0:
+        np.savez(os.environ["DIST_OUT"], x=res.x, grad_norm=np.array(res.grad_norm), same=same,
+                 units=np.array([len(u) for u in fus.assignment]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
