@@ -49,7 +49,9 @@ typedef struct {
     const int32_t *grid_i1;            /* [P][na*nb] lower beta index                               */
     const double *grid_y0;             /* [P][na*nb] normalised alpha distance                      */
     const double *grid_y1;             /* [P][na*nb] normalised beta distance                       */
-    const double *wpsf;                /* [Ldet][Lin][n_beta_slit] spectral PSF (instru.py:499-572) */
+    const double *wpsf;                /* [Ldet][Lin][n_beta_slit] spectral PSF (instru.py:499-572);
+                                          NULL: no spectral blur, y[l][(p,s,a)] = sum over the slit's beta
+                                          columns (MRSBlurred, spectro_blind_rectangle.py:193-209)           */
     /* reference-compatible back-interpolation tables for surfh_adjoint_ref (gridding_t,
        spectroModelChannel.py:180-199); may be NULL if adjoint_ref is never called.               */
     const int32_t *gt_i0;              /* [P][Na*Nb] lower local alpha index                        */

@@ -173,6 +173,14 @@ def find_indices(axis, values):
     return idx.astype(np.int64), frac
 
 
+def nearest_index(axis, values):
+    """Index of the nearest axis sample (what the cKDTree query of
+    nearest_neighbor_interpolation.py:16-20,177,199 returns on a separable grid)."""
+    axis = np.asarray(axis, dtype=np.float64)
+    v = np.asarray(values, dtype=np.float64).ravel()
+    return np.abs(axis[None, :] - v[:, None]).argmin(axis=1)
+
+
 def bilinear_apply(cube, i0, i1, y0, y1):
     """solve_2D_hypercube (cythons_files.pyx:163-193): same weights, same order."""
     w1 = (1.0 - y0) * (1.0 - y1)
@@ -221,6 +229,9 @@ class ChannelTables:
     oshape: Tuple[int, int, int, int]
     grid_idx: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)   # per pointing (i0, i1) [na*nb]
     grid_frac: List[Tuple[np.ndarray, np.ndarray]] = field(default_factory=list)  # per pointing (y0, y1)
+    nn_idx: List[np.ndarray] = field(default_factory=list)     # per pointing: flat C-order cube index [na*nb]
+    nn_idx_t: List[np.ndarray] = field(default_factory=list)   # per pointing: flat local index per cube pixel [Na*Nb]
+    gridding: str = "bilinear"
 
 
 def _slit_local_fov(spec: ChannelSpec, s: int):
@@ -286,7 +297,7 @@ def _fov_weight(fovb, sl, la, lb):
 
 
 def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_degree,
-                  pointings: Sequence[Tuple[float, float]], with_grid=True) -> ChannelTables:
+                  pointings: Sequence[Tuple[float, float]], with_grid=True, gridding="bilinear") -> ChannelTables:
     """Everything Channel.__init__ / Slicer derive (spectroModelChannel.py:27-108)."""
     srf = get_srf(spec.det_pix_size, step_degree * 3600)               # spectroModel.py:67-70
     origin_pix = (pix(spec.origin[0], step_degree), pix(spec.origin[1], step_degree))   # IFU.pix
@@ -332,6 +343,17 @@ def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_deg
             i1, y1 = find_indices(beta_axis, gb.ravel())
             tab.grid_idx.append((i0, i1))
             tab.grid_frac.append((y0, y1))
+            if gridding != "bilinear":
+                # NN index recipe of Channel.precompute_mask (spectroModelChannel.py:399-415).  The reference forms
+                # k = i_beta*N + i_alpha and applies it to the C-order cube ("nn_ref"); "nn" is the untransposed form.
+                N = len(beta_axis)
+                ia, ib = nearest_index(alpha_axis, ga), nearest_index(beta_axis, gb)
+                tab.nn_idx.append(ib * N + ia if gridding == "nn_ref" else ia * N + ib)
+                ca, cb = global2local(alpha_axis, beta_axis, spec.angle, (origin_pix[0] + p[0], origin_pix[1] + p[1]))
+                if gridding == "nn_ref":
+                    ca, cb = ca.T, cb.T
+                tab.nn_idx_t.append(nearest_index(la, ca) * len(lb) + nearest_index(lb, cb))
+    tab.gridding = gridding
     return tab
 
 
@@ -340,14 +362,19 @@ def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_deg
 # ----------------------------------------------------------------------------
 def gridding(tab: ChannelTables, sub_cube, p):
     """Channel.gridding (:158-177): bilinear cube -> rotated local grid."""
-    (i0, i1), (y0, y1) = tab.grid_idx[p], tab.grid_frac[p]
     na, nb = len(tab.local_alpha_axis), len(tab.local_beta_axis)
+    if tab.gridding != "bilinear":       # NN_gridding (:201-205)
+        return sub_cube.reshape(sub_cube.shape[0], -1)[:, tab.nn_idx[p]].reshape(sub_cube.shape[0], na, nb)
+    (i0, i1), (y0, y1) = tab.grid_idx[p], tab.grid_frac[p]
     return bilinear_apply(sub_cube, i0, i1, y0, y1).reshape(sub_cube.shape[0], na, nb)
 
 
 def gridding_t_ref(tab: ChannelTables, local_cube, p, alpha_axis, beta_axis):
     """Channel.gridding_t (:180-199): the reference's *interpolating* back-projection
     (bilinear local -> global, 0 outside).  NOT the transpose of ``gridding``."""
+    if tab.gridding != "bilinear":       # NN_gridding_t (:208-212): gather back, no support mask
+        L = local_cube.shape[0]
+        return local_cube.reshape(L, -1)[:, tab.nn_idx_t[p]].reshape(L, len(alpha_axis), len(beta_axis))
     org = (tab.origin_pix[0] + tab.pointings[p][0], tab.origin_pix[1] + tab.pointings[p][1])
     ca, cb = global2local(alpha_axis, beta_axis, tab.spec.angle, org)
     la, lb = tab.local_alpha_axis, tab.local_beta_axis
@@ -361,10 +388,14 @@ def gridding_t_ref(tab: ChannelTables, local_cube, p, alpha_axis, beta_axis):
 
 def gridding_T(tab: ChannelTables, local_cube, p, n_alpha, n_beta):
     """Exact transpose of ``gridding`` (scatter-add of the same four weights)."""
-    (i0, i1), (y0, y1) = tab.grid_idx[p], tab.grid_frac[p]
     L = local_cube.shape[0]
     v = local_cube.reshape(L, -1)
     out = np.zeros((L, n_alpha * n_beta))
+    if tab.gridding != "bilinear":       # transpose of the index gather = scatter-add
+        for l in range(L):
+            out[l] = np.bincount(tab.nn_idx[p], weights=v[l], minlength=n_alpha * n_beta)
+        return out.reshape(L, n_alpha, n_beta)
+    (i0, i1), (y0, y1) = tab.grid_idx[p], tab.grid_frac[p]
     for di, dj, w in ((0, 0, (1 - y0) * (1 - y1)), (0, 1, (1 - y0) * y1),
                       (1, 0, y0 * (1 - y1)), (1, 1, y0 * y1)):
         flat = (i0 + di) * n_beta + (i1 + dj)
@@ -491,7 +522,7 @@ class OracleModel:
     """spectroSigRLSCT (spectroModel.py:39-185) in float64."""
 
     def __init__(self, sotf, templates, alpha_axis, beta_axis, wavelength_axis,
-                 specs: Sequence[ChannelSpec], step_degree, pointings, box="fft"):
+                 specs: Sequence[ChannelSpec], step_degree, pointings, box="fft", gridding="bilinear"):
         self.sotf = np.asarray(sotf)
         self.templates = None if templates is None else np.asarray(templates, dtype=np.float64)
         self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
@@ -499,7 +530,7 @@ class OracleModel:
         self.wavelength_axis = np.asarray(wavelength_axis, dtype=np.float64)
         self.box = box
         self.channels = [build_channel(sp, self.alpha_axis, self.beta_axis, self.wavelength_axis,
-                                       step_degree, pointings[k]) for k, sp in enumerate(specs)]
+                                       step_degree, pointings[k], gridding=gridding) for k, sp in enumerate(specs)]
         n_lead = self.templates.shape[0] if self.templates is not None else len(self.wavelength_axis)
         self.ishape = (n_lead, len(self.alpha_axis), len(self.beta_axis))
         self.cube_shape = (len(self.wavelength_axis), len(self.alpha_axis), len(self.beta_axis))
@@ -664,3 +695,89 @@ def dither4(det_pix_size_arcsec, slit_beta_width_deg):
     da = (det_pix_size_arcsec / 3600) / 4
     db = slit_beta_width_deg / 4
     return [(da, db), (-da, db), (da, -db), (-da, -db)]
+
+
+# ----------------------------------------------------------------------------
+# 2-D single-wavelength operator without rotation: MRSBlurred
+# (surfh/Models/spectro_blind_rectangle.py:27-332)
+# ----------------------------------------------------------------------------
+class BlurredOracle:
+    """``MRSBlurred``: C (2-D OTF), integer-crop gridding, srf-row window sum, slit window with beta-edge
+    weights, alpha decimation, beta sum.  ``sotf`` may carry a leading wavelength axis: the planes are
+    independent and are processed as a batch (BASELINE.json configs[4])."""
+
+    def __init__(self, sotf, alpha_axis, beta_axis, spec: ChannelSpec, step_degree, pointings):
+        self.sotf = np.asarray(sotf)
+        self.batched = self.sotf.ndim == 3
+        self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
+        self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
+        self.spec, self.pointings = spec, list(pointings)        # NOT pixelised (:38-39)
+        self.srf = get_srf(spec.det_pix_size, step_degree * 3600)
+        self.la = fov_local_axis(spec.alpha_width, 5 * step_degree, step_degree)
+        self.lb = fov_local_axis(spec.beta_width, 5 * step_degree, step_degree)
+        lstep = self.la[1] - self.la[0]
+        self.npix_a = int(ceil(spec.alpha_width / 2 / lstep)) - int(floor(-spec.alpha_width / 2 / lstep))   # :90-98
+        self.npix_b = int(ceil((spec.beta_width / spec.n_slit) / (self.beta_axis[1] - self.beta_axis[0])))   # :105-108
+        self.n_out = ceil(self.npix_a / self.srf)
+        self.slices_shape = (len(self.pointings), spec.n_slit, self.n_out)
+        self.ishape = (len(self.alpha_axis), len(self.beta_axis))
+        self.slit_slices, self.slit_weights = [], []
+        for s in range(spec.n_slit):                              # get_slit_slices (:122-149): beta trim only
+            fovb = _slit_local_fov(spec, s)
+            a0, a1, b0, b1 = _to_slices(fovb, self.la, self.lb)
+            if (b1 - b0) > self.npix_b:
+                if abs(self.lb[b1] - fovb[3]) > abs(self.lb[b0] - fovb[2]):
+                    b1 -= 1
+                else:
+                    b0 += 1
+            self.slit_slices.append((a0, a1, b0, b1))
+        for s, sl in enumerate(self.slit_slices):                 # get_slit_weights (:152-172)
+            w = _fov_weight(_slit_local_fov(spec, s), sl, self.la, self.lb)
+            if s > 0 and self.slit_slices[s - 1][3] - 1 != sl[2]:
+                w[:, 0] = 1
+            if s < self.npix_b - 1:       # the reference compares with npix_slit_beta_width, not n_slit (:167):
+                if sl[3] - 1 != self.slit_slices[s + 1][2]:       # slits >= npix_b-1 keep their fractional last column,
+                    w[:, -1] = 1                                  # and n_slit < npix_b raises IndexError as there
+            self.slit_weights.append(w)
+        self.crops = []
+        for p in self.pointings:                                  # gridding (:286-307)
+            ia = int(np.abs(self.alpha_axis - p[0]).argmin())
+            ib = int(np.abs(self.beta_axis - p[1]).argmin())
+            self.crops.append((ia - len(self.la) // 2, ia + len(self.la) // 2 + 1,
+                               ib - len(self.lb) // 2, ib + len(self.lb) // 2 + 1))
+
+    def _box(self, img, t=False):
+        sh = 1 if t else -1
+        return sum(np.roll(img, sh * j, axis=-2) for j in range(self.srf))
+
+    def forward(self, x):
+        x = np.asarray(x, dtype=np.float64)
+        xb = x if self.batched else x[None]
+        sf = self.sotf if self.batched else self.sotf[None]
+        blurred = idft(dft(xb) * sf, self.ishape)
+        out = np.zeros((xb.shape[0],) + self.slices_shape)
+        for p, (a0, a1, b0, b1) in enumerate(self.crops):
+            ss = self._box(blurred[:, a0:a1, b0:b1])
+            for s, (sa0, sa1, sb0, sb1) in enumerate(self.slit_slices):
+                sl = ss[:, sa0:sa1, sb0:sb1] * self.slit_weights[s][None]
+                out[:, p, s] = np.sum(sl[:, : self.n_out * self.srf: self.srf], axis=2)
+        out = out.reshape(xb.shape[0], -1)
+        return out if self.batched else out[0]
+
+    def adjoint(self, data):
+        data = np.asarray(data, dtype=np.float64)
+        L = self.sotf.shape[0] if self.batched else 1
+        d = data.reshape((L,) + self.slices_shape)
+        g = np.zeros((L,) + self.ishape)
+        na, nb = len(self.la), len(self.lb)
+        for p, (a0, a1, b0, b1) in enumerate(self.crops):
+            local = np.zeros((L, na, nb))
+            for s, (sa0, sa1, sb0, sb1) in enumerate(self.slit_slices):
+                over = np.repeat(d[:, p, s][:, :, None], self.npix_b, axis=2)
+                bts = np.zeros((L, sa1 - sa0, sb1 - sb0))
+                bts[:, : self.n_out * self.srf: self.srf, :] = over
+                local[:, sa0:sa1, sb0:sb1] += bts * self.slit_weights[s][None]
+            g[:, a0:a1, b0:b1] += self._box(local, t=True)
+        sf = self.sotf if self.batched else self.sotf[None]
+        out = idft(dft(g) * sf.conj(), self.ishape)
+        return out if self.batched else out[0]

@@ -81,6 +81,7 @@ struct Channel {
     float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
     DevEll fwd, adjT, adjRef;
     bool has_ref = false;
+    bool bsum = false;   // no spectral blur: y[l][(p,s,a)] = sum over the slit's beta columns (MRSBlurred)
 };
 
 struct ProfRec {
@@ -233,8 +234,10 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     if (c->P < 1 || c->S < 1 || c->Ldet < 1 || c->aout < 1 || c->srf < 1 || c->nbs < 1) return fail("bad channel dims");
     if ((c->aout - 1) * c->srf >= c->nas) return fail("decimation (alpha_out-1)*srf=%d exceeds the slit alpha window %d", (c->aout - 1) * c->srf, c->nas);
     if (c->alpha0 < 0 || c->alpha0 + c->nas > c->na) return fail("slit alpha window outside the local grid");
-    if (!d.slit_beta0 || !d.slit_weights || !d.grid_i0 || !d.grid_i1 || !d.grid_y0 || !d.grid_y1 || !d.wpsf)
+    if (!d.slit_beta0 || !d.slit_weights || !d.grid_i0 || !d.grid_i1 || !d.grid_y0 || !d.grid_y1)
         return fail("channel table pointer is NULL");
+    c->bsum = (d.wpsf == nullptr);
+    if (c->bsum) c->Ldet = c->Lin;
     for (int s = 0; s < c->S; ++s)
         if (d.slit_beta0[s] < 0 || d.slit_beta0[s] + c->nbs > c->nb) return fail("slit %d beta window outside the local grid", s);
     // wavelength window inside the plan's planes, start aligned to 4 floats for 16-byte vector access
@@ -243,7 +246,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     c->LinA = (c->ws1 - p->lo) - c->ws0a;
     c->LinP = pad64(c->LinA);
     c->nlam = (c->LinA + 3) / 4 * 4;
-    c->K = c->nbs * c->LinP;
+    c->K = (c->bsum ? 1 : c->nbs) * c->LinP;
     c->NP = pad64(c->P * c->S * c->aout);
     c->LdetP = pad64(c->Ldet);
     c->ysize = (long)c->P * c->S * c->Ldet * c->aout;
@@ -258,7 +261,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     const int64_t LP = p->LP;
     auto pix_off = [&](int ia, int ib) -> int64_t { return ((int64_t)ib * p->NAP + ia) * LP + c->ws0a; };
     auto xs_off = [&](int pt, int s, int a, int b) -> int64_t {
-        return ((int64_t)((pt * c->S + s) * c->aout + a)) * c->K + (int64_t)b * c->LinP;
+        return ((int64_t)((pt * c->S + s) * c->aout + a)) * c->K + (c->bsum ? 0 : (int64_t)b * c->LinP);
     };
 
     // ---- forward rows (p, a, j-order over (s,b')): S + box-sum + slit window + decimation -------
@@ -281,11 +284,25 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                         const double y0 = d.grid_y0[li], y1 = d.grid_y1[li];
                         const double w[4] = {(1. - y0) * (1. - y1), (1. - y0) * y1, y0 * (1. - y1), y0 * y1};
                         const int da[4] = {0, 0, 1, 1}, db[4] = {0, 1, 0, 1};
-                        for (int k = 0; k < 4; ++k) row.push_back({pix_off(i0 + da[k], i1 + db[k]), (float)(w[k] * ws)});
+                        for (int k = 0; k < 4; ++k)
+                            if (w[k] * ws != 0.0) row.push_back({pix_off(i0 + da[k], i1 + db[k]), (float)(w[k] * ws)});
                     }
                     f.rows.push_back(std::move(row));
                     f.dst.push_back(xs_off(pt, s, a, b));
                 }
+    if (c->bsum) {   // rows that share a destination (the slit's beta columns) are merged into one
+        std::map<int64_t, std::map<int64_t, double>> mg;
+        for (size_t r = 0; r < f.rows.size(); ++r)
+            for (auto &e : f.rows[r]) mg[f.dst[r]][e.first] += (double)e.second;
+        HostEll f2;
+        for (auto &row : mg) {
+            std::vector<std::pair<int64_t, float>> v;
+            for (auto &e : row.second) v.push_back({e.first, (float)e.second});
+            f2.rows.push_back(std::move(v));
+            f2.dst.push_back(row.first);
+        }
+        f = std::move(f2);
+    }
     if (upload_ell(f, &c->fwd)) return 1;
 
     // ---- exact transpose: rows = touched cube pixels ------------------------------------------
@@ -324,6 +341,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                     const double w[4] = {(1. - y0) * (1. - y1), (1. - y0) * y1, y0 * (1. - y1), y0 * y1};
                     const int li[4] = {i0, i0, i0 + 1, i0 + 1}, lj[4] = {i1, i1 + 1, i1, i1 + 1};
                     for (int k = 0; k < 4; ++k)
+                        if (w[k] != 0.0)
                         for (int a : arow[li[k]])
                             for (auto &sb : colslit[lj[k]])
                                 m[xs_off(pt, sb.first, a, sb.second)] += w[k] * d.slit_weights[(long)sb.first * c->nbs + sb.second];
@@ -338,7 +356,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     }
 
     // ---- spectral PSF as GEMM operands: W[l'][b'*LinP + shift + l] = wpsf[l'][l][b'] -------------
-    {
+    if (!c->bsum) {
         std::vector<float> W((size_t)c->LdetP * c->K, 0.f), Wt((size_t)c->K * c->LdetP, 0.f);
         for (int l = 0; l < c->Ldet; ++l)
             for (int lam = 0; lam < c->Lin; ++lam)
@@ -352,8 +370,10 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     }
     if (dev_alloc(&c->Xs, (size_t)c->NP * c->K)) return 1;
     HIP_OK(hipMemset(c->Xs, 0, (size_t)c->NP * c->K * sizeof(float)));
-    if (dev_alloc(&c->ymat, (size_t)c->NP * c->LdetP)) return 1;
-    HIP_OK(hipMemset(c->ymat, 0, (size_t)c->NP * c->LdetP * sizeof(float)));
+    if (!c->bsum) {
+        if (dev_alloc(&c->ymat, (size_t)c->NP * c->LdetP)) return 1;
+        HIP_OK(hipMemset(c->ymat, 0, (size_t)c->NP * c->LdetP * sizeof(float)));
+    }
     return 0;
 }
 
@@ -607,6 +627,11 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             Prof pr(p, "spmm_gather_fwd");
             LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0));
         }
+        if (c.bsum) {   // y[l][(p,s,a)] = Xs[(p,s,a)][l]
+            Prof pr(p, "y_transpose");
+            LAUNCH_OK(launch_cube_from_lam_inner(s, c.Xs + c.shift, y + c.yoff, 0, c.Lin, 1, c.P * c.S * c.aout, 1, c.LinP));
+            continue;
+        }
         GemmArgs g;   // y^T[n][l'] = Xs[n][k] Wt[k][l']
         g.A0 = c.Xs; g.lda = c.K;
         g.B0 = c.Wt; g.ldb = c.LdetP;
@@ -633,6 +658,15 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
     }
     for (auto &c : p->ch) {
         if (ref && !c.has_ref) return fail("adjoint_ref needs the gridding_t tables (gt_*) in the channel descriptor");
+        if (c.bsum) {
+            {
+                Prof pr(p, "y_transpose");
+                LAUNCH_OK(launch_cube_to_lam_inner(s, y + c.yoff, c.Xs + c.shift, 0, c.Lin, 1, c.P * c.S * c.aout, 1, c.LinP));
+            }
+            Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
+            LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+            continue;
+        }
         {
             Prof pr(p, "ymat_from_y");
             LAUNCH_OK(launch_ymat_from_y(s, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP));
@@ -856,6 +890,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         Channel &c = p->ch[i];
         c.yoff = yoff;
         yoff += c.ysize;
+        if (c.bsum) continue;
         c.splitK = pick_split(c, cfg->split_k_forward);
         if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
         hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));

@@ -129,11 +129,26 @@ def find_indices(axis, values):
     return idx.astype(np.int32), (v - axis[idx]) / (axis[idx + 1] - axis[idx])
 
 
+def nearest_indices(axis, values):
+    """Nearest-sample selection written as a degenerate (index, fraction) pair: the fraction is exactly
+    0 or 1, so the bilinear machinery (and its exact transpose) applies the nearest-neighbour gather
+    of NN_gridding (spectroModelChannel.py:201-212) without a second code path."""
+    axis = np.asarray(axis, dtype=np.float64)
+    v = np.asarray(values, dtype=np.float64)
+    near = np.abs(axis[None, :] - v[:, None]).argmin(axis=1) if v.size * axis.size < 5e7 else \
+        np.clip(np.rint((v - axis[0]) / (axis[1] - axis[0])), 0, len(axis) - 1).astype(np.int64)
+    lo = np.minimum(near, len(axis) - 2)
+    return lo.astype(np.int32), (near - lo).astype(np.float64)
+
+
 class ChannelGeometry:
     """Host description of one channel (spectroModelChannel.py:27-108), no arithmetic on cubes."""
 
     def __init__(self, instr: instru.IFU, alpha_axis, beta_axis, wavel_axis, srf: int,
-                 pointings: instru.CoordList, step_degree: float):
+                 pointings: instru.CoordList, step_degree: float, gridding: str = "bilinear"):
+        if gridding not in ("bilinear", "nn", "nn_ref"):
+            raise ValueError("gridding must be 'bilinear', 'nn' or 'nn_ref'")
+        self.gridding_mode = gridding
         self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
         self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
         self.global_wavelength_axis = np.asarray(wavel_axis, dtype=np.float64)
@@ -178,18 +193,37 @@ class ChannelGeometry:
         for dim, (ax, v) in enumerate(((self.alpha_axis, ga), (self.beta_axis, gb))):
             if not (np.all(ax[0] <= v) and np.all(v <= ax[-1])):
                 raise ValueError("One of the requested xi is out of bounds in dimension %d" % dim)
-        i0, y0 = find_indices(self.alpha_axis, ga.ravel())
-        i1, y1 = find_indices(self.beta_axis, gb.ravel())
+        if self.gridding_mode == "bilinear":
+            i0, y0 = find_indices(self.alpha_axis, ga.ravel())
+            i1, y1 = find_indices(self.beta_axis, gb.ravel())
+        elif self.gridding_mode == "nn":
+            i0, y0 = nearest_indices(self.alpha_axis, ga.ravel())
+            i1, y1 = nearest_indices(self.beta_axis, gb.ravel())
+        else:
+            # the reference's index recipe (spectroModelChannel.py:399-407) builds k = i_beta*N + i_alpha and
+            # applies it to the C-order cube, i.e. it reads pixel [i_beta, i_alpha]: kept under "nn_ref"
+            if len(self.alpha_axis) != len(self.beta_axis):
+                raise ValueError("gridding='nn_ref' needs a square cube")
+            i0, y0 = nearest_indices(self.beta_axis, gb.ravel())
+            i1, y1 = nearest_indices(self.alpha_axis, ga.ravel())
         return i0, i1, y0, y1
 
     def gridt_tables(self, p: int):
-        """Tables of the reference's interpolating ``gridding_t`` (spectroModelChannel.py:180-199)."""
+        """Tables of the reference's back-projection: interpolating ``gridding_t``
+        (spectroModelChannel.py:180-199), or for the NN modes the nearest local pixel of every cube
+        pixel (``NN_gridding_t``, :208-212, :411-415 -- no support mask, as in the reference)."""
         ca, cb = (self.instr.fov + self.pointings[p]).global2local(self.alpha_axis, self.beta_axis)
         la, lb = self.local_alpha_axis, self.local_beta_axis
-        i0, y0 = find_indices(la, ca.ravel())
-        i1, y1 = find_indices(lb, cb.ravel())
-        inside = ~((ca.ravel() < la[0]) | (ca.ravel() > la[-1]) | (cb.ravel() < lb[0]) | (cb.ravel() > lb[-1]))
-        return i0, i1, y0, y1, inside.astype(np.uint8)
+        if self.gridding_mode == "bilinear":
+            i0, y0 = find_indices(la, ca.ravel())
+            i1, y1 = find_indices(lb, cb.ravel())
+            inside = ~((ca.ravel() < la[0]) | (ca.ravel() > la[-1]) | (cb.ravel() < lb[0]) | (cb.ravel() > lb[-1]))
+            return i0, i1, y0, y1, inside.astype(np.uint8)
+        if self.gridding_mode == "nn_ref":      # global pixel [i, j] is read as the point (alpha_j, beta_i)
+            ca, cb = ca.T.copy(), cb.T.copy()
+        i0, y0 = nearest_indices(la, ca.ravel())
+        i1, y1 = nearest_indices(lb, cb.ravel())
+        return i0, i1, y0, y1, np.ones(ca.size, dtype=np.uint8)
 
     def tables(self, with_ref: bool = True) -> dict:
         """Flat C-contiguous arrays in the layout of ``surfh_channel_desc``."""

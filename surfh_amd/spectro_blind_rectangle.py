@@ -1,0 +1,172 @@
+"""``MRSBlurred``: the 2-D, no-rotation operator of the reference's deconvolution path
+(surfh/Models/spectro_blind_rectangle.py:27-332, driver scripts/deconvolution_mrs_noRotation.py:170-212)
+evaluated by the HIP library.
+
+    y[p, s, a] = sum_beta  w_s[beta] * boxsum_alpha(crop_p(C x))[alpha0 + a*srf, beta]
+
+C = 2-D OTF multiply, crop = integer-shift gridding (:286-307), box-sum = srf consecutive alpha rows
+(:201-204), slit window with beta-edge weights, alpha decimation and beta sum (:206-208).  The crop is
+exactly transposable, so ``adjoint`` is both the exact transpose and the reference's adjoint (:212-237).
+
+``sotf`` may be ``[N_alpha, N_beta/2+1]`` (the reference's single image) or
+``[L, N_alpha, N_beta/2+1]``: the L wavelength planes are independent problems evaluated as one batch
+(BASELINE.json configs[4]); ``forward`` then maps ``[L, N_alpha, N_beta] -> [L, P*S*alpha_out]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from math import ceil, floor
+
+import numpy as np
+
+from . import _lib, instru
+from .linop import LinOp
+
+
+class MRSBlurred(LinOp):
+    def __init__(self, sotf, alpha_axis, beta_axis, instr: instru.IFU, step_degree: float,
+                 pointings: instru.CoordList, *, device: int = 0, stream=None):
+        self.sotf = sotf
+        self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
+        self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
+        self.step_degree = step_degree
+        self.instr = instr                    # not pixelised, as in the reference (:38-39)
+        self.pointings = pointings
+        self.srf = instru.get_srf([instr.det_pix_size], step_degree * 3600)[0]
+        self.local_alpha_axis, self.local_beta_axis = instr.fov.local_coords(step_degree, 5 * step_degree, 5 * step_degree)
+        self.local_im_shape = (len(self.local_alpha_axis), len(self.local_beta_axis))
+        self.imshape = (len(self.alpha_axis), len(self.beta_axis))
+        self.slices_shape = (len(pointings), instr.n_slit, ceil(self.npix_slit_alpha_width / self.srf))
+        sotf_c = np.ascontiguousarray(sotf, dtype=np.complex128)
+        self.batched = sotf_c.ndim == 3
+        if not self.batched:
+            sotf_c = sotf_c[None]
+        self.n_planes = sotf_c.shape[0]
+        if sotf_c.shape[1:] != (self.imshape[0], self.imshape[1] // 2 + 1):
+            raise ValueError(f"sotf plane shape {sotf_c.shape[1:]} does not match the image {self.imshape}")
+        n_out = int(np.prod(self.slices_shape))
+        super().__init__(ishape=((self.n_planes,) if self.batched else ()) + self.imshape,
+                         oshape=((self.n_planes, n_out) if self.batched else (n_out,)))
+
+        # ---- tables ---------------------------------------------------------------------------
+        S = instr.n_slit
+        slices = [self.get_slit_slices(s) for s in range(S)]
+        nbs = self.npix_slit_beta_width
+        a0, a1 = slices[0][0].start, slices[0][0].stop
+        weights = np.empty((S, nbs))
+        for s, sl in enumerate(slices):
+            if (sl[0].start, sl[0].stop) != (a0, a1) or sl[1].stop - sl[1].start != nbs:
+                raise ValueError(f"slit {s}: window {sl} differs from slit 0 / npix_slit_beta_width={nbs}")
+            weights[s] = self.get_slit_weights(s, sl)[0][0]
+        na, nb = self.local_im_shape
+        P = len(pointings)
+        i0 = np.empty((P, na * nb), dtype=np.int32)
+        i1 = np.empty_like(i0)
+        y0 = np.empty((P, na * nb), dtype=np.float64)
+        y1 = np.empty_like(y0)
+        self.crops = []
+        for p, pt in enumerate(pointings):          # integer crop (:286-307) written as degenerate bilinear taps
+            ia = int(np.abs(self.alpha_axis - pt.alpha).argmin())
+            ib = int(np.abs(self.beta_axis - pt.beta).argmin())
+            sa, sb = ia - na // 2, ib - nb // 2
+            if sa < 0 or sb < 0 or sa + na > self.imshape[0] or sb + nb > self.imshape[1] or na % 2 == 0 or nb % 2 == 0:
+                raise ValueError(f"pointing {p}: the {na}x{nb} field of view does not fit in the {self.imshape} image")
+            self.crops.append((sa, sa + na, sb, sb + nb))
+            ra = np.repeat(np.arange(sa, sa + na), nb)
+            rb = np.tile(np.arange(sb, sb + nb), na)
+            la, lb = np.minimum(ra, self.imshape[0] - 2), np.minimum(rb, self.imshape[1] - 2)
+            i0[p], i1[p], y0[p], y1[p] = la, lb, ra - la, rb - lb
+        self._tab = dict(slit_beta0=np.ascontiguousarray([sl[1].start for sl in slices], dtype=np.int32),
+                         slit_weights=np.ascontiguousarray(weights), i0=i0, i1=i1, y0=y0, y1=y1)
+        d = _lib.ChannelDesc()
+        d.wslice_start, d.wslice_stop = 0, self.n_planes
+        d.n_pointings, d.n_slit, d.n_lambda_out, d.n_alpha_out, d.srf = P, S, self.n_planes, self.slices_shape[2], self.srf
+        d.na, d.nb, d.alpha0, d.n_alpha_slit, d.n_beta_slit = na, nb, a0, a1 - a0, nbs
+        d.slit_beta0, d.slit_weights = _lib.iptr(self._tab["slit_beta0"]), _lib.dptr(self._tab["slit_weights"])
+        d.grid_i0, d.grid_i1, d.grid_y0, d.grid_y1 = _lib.iptr(i0), _lib.iptr(i1), _lib.dptr(y0), _lib.dptr(y1)
+        d.wpsf = None                                # beta-sum mode (no spectral blur)
+        cfg = _lib.Config()
+        cfg.n_alpha, cfg.n_beta, cfg.n_lambda, cfg.n_templates = self.imshape[0], self.imshape[1], self.n_planes, 0
+        cfg.templates = None
+        cfg.sotf = sotf_c.view(np.float64).ctypes.data_as(_lib.c_double_p)
+        cfg.n_channels, cfg.channels = 1, C.pointer(d)
+        cfg.device, cfg.stream, cfg.split_k_forward = device, (C.c_void_p(stream) if stream else None), 0
+        L = _lib.load()
+        plan = C.c_void_p()
+        _lib.check(L.surfh_plan_create(C.byref(cfg), C.byref(plan)), ValueError)
+        self._L, self._plan = L, plan
+        assert L.surfh_isize(plan) == self.isize and L.surfh_osize(plan) == self.osize
+
+    def close(self):
+        if getattr(self, "_plan", None):
+            self._L.surfh_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- geometry (same rules as the reference class) -----------------------------------------------
+    @property
+    def npix_slit_alpha_width(self) -> int:
+        step = self.local_alpha_axis[1] - self.local_alpha_axis[0]
+        half = self.instr.fov.alpha_width / 2 / step
+        return int(ceil(half)) - int(floor(-half))
+
+    @property
+    def slit_beta_width(self):
+        return self.instr.fov.beta_width / self.instr.n_slit
+
+    @property
+    def npix_slit_beta_width(self) -> int:
+        return int(ceil(self.slit_beta_width / (self.beta_axis[1] - self.beta_axis[0])))
+
+    def slit_local_fov(self, slit_idx: int):
+        return self.instr.slit_fov[slit_idx].local + self.instr.slit_shift[slit_idx]
+
+    def get_slit_slices(self, slit_idx: int):
+        """Beta trimming only: the alpha-length rule of Slicer is commented out here (:122-149)."""
+        lf = self.slit_local_fov(slit_idx)
+        sa, sb = lf.to_slices(self.local_alpha_axis, self.local_beta_axis)
+        if sb.stop - sb.start > self.npix_slit_beta_width:
+            far_end = abs(self.local_beta_axis[sb.stop] - lf.beta_end)
+            far_start = abs(self.local_beta_axis[sb.start] - lf.beta_start)
+            sb = slice(sb.start, sb.stop - 1) if far_end > far_start else slice(sb.start + 1, sb.stop)
+        return sa, sb
+
+    def get_slit_weights(self, slit_idx: int, slices):
+        sa, sb = slices
+        lf = self.slit_local_fov(slit_idx)
+        db = self.local_beta_axis[1] - self.local_beta_axis[0]
+        sel = self.local_beta_axis[sb]
+        w = np.ones((sa.stop - sa.start, sb.stop - sb.start))
+        if sel[0] - db / 2 < lf.beta_start:
+            w[:, 0] = 1 - abs(sel[0] - db / 2 - lf.beta_start) / db
+        if sel[-1] + db / 2 > lf.beta_end:
+            w[:, -1] = 1 - abs(sel[-1] + db / 2 - lf.beta_end) / db
+        assert np.all((0 <= w) & (w <= 1))
+        if slit_idx > 0 and self.get_slit_slices(slit_idx - 1)[1].stop - 1 != sb.start:
+            w[:, 0] = 1
+        # the reference bounds this test by npix_slit_beta_width, not n_slit (:167): kept, including
+        # its IndexError when there are fewer slits than beta columns
+        if slit_idx < self.npix_slit_beta_width - 1:
+            if sb.stop - 1 != self.get_slit_slices(slit_idx + 1)[1].start:
+                w[:, -1] = 1
+        return w[np.newaxis, ...]
+
+    # ---- operator -------------------------------------------------------------------------------------
+    def _call(self, fn, x, nin, shape_out):
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+        if a.size != nin:
+            raise ValueError(f"input has {a.size} elements, expected {nin}")
+        out = np.empty(int(np.prod(shape_out)), dtype=np.float32)
+        _lib.check(fn(self._plan, _lib.fptr(a), _lib.fptr(out)))
+        return out.astype(np.float64).reshape(shape_out)
+
+    def forward(self, x):
+        return self._call(self._L.surfh_forward, x, self.isize, self.oshape)
+
+    def adjoint(self, data):
+        return self._call(self._L.surfh_adjoint, data, self.osize, self.ishape)

@@ -121,6 +121,19 @@ def main():
     np.savez_compressed(os.path.join(HERE, "config1_chain.npz"), **d)
     print("config1: ||y|| =", np.linalg.norm(y), "oshape", ch.oshape)
 
+    # ---------------- nearest-neighbour index tables (precompute_mask recipe) ----------------
+    # spectroModelChannel.py:399-413 + nearest_neighbor_interpolation.griddata (cKDTree indices).
+    N = cfg["N"]
+    nn = {}
+    for p, pointing in enumerate(ch.pointings):
+        la, lb = (ch.instr.fov + pointing).local2global(ch.local_alpha_axis, ch.local_beta_axis)
+        ta = np.tile(ch.alpha_axis, N)
+        tb = np.repeat(ch.beta_axis, N)
+        nn[f"nn_idx_p{p}"] = np.asarray(ns.nn.griddata((ta.ravel(), tb.ravel()), np.ones(N * N), (la, lb))).astype(np.int32)
+        nn[f"nn_idx_t_p{p}"] = np.asarray(ns.nn.griddata((la.ravel(), lb.ravel()), np.ones(la.size),
+                                                          (ta.reshape(N, N), tb.reshape(N, N)))).astype(np.int32)
+    np.savez_compressed(os.path.join(HERE, "config1_nn_indices.npz"), **nn)
+
     # ---------------- two overlapping channels ----------------
     cfg2 = problems.two_channel_small()
     rm2 = ref_model(ns, cfg2)
@@ -172,5 +185,30 @@ def main():
     np.savez_compressed(os.path.join(HERE, "bands_geometry.npz"), **g)
 
 
+def blurred():
+    """MRSBlurred (surfh/Models/spectro_blind_rectangle.py) on a 96x96 image, 12 slits, 3 integer-shift pointings."""
+    import importlib
+    ns = rh.load()
+    mod = importlib.import_module("surfh.Models.spectro_blind_rectangle")
+    orc = problems.orc
+    N = 96
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    spec = orc.ChannelSpec(1.0 / 3600, 1.2 / 3600, (0.0, 0.0), 0.0, 0.196, 12, 3000.0, np.linspace(7, 8, 10), "R")
+    sotf = orc.ir2fr(orc.gaussian_psf(np.array([7.6]), problems.STEP), (N, N))[0]
+    s = problems.STEP_DEG
+    pts = [(0.0, 0.0), (2 * s, -3 * s), (-4 * s, 1 * s)]
+    I = ns.instru
+    rm = mod.MRSBlurred(sotf, ax, ax, rh.make_ifu(ns, spec), s, I.CoordList([I.Coord(a, b) for a, b in pts]))
+    x = np.random.default_rng(3).random((N, N))
+    y = rm.forward(x)
+    u = np.random.default_rng(4).standard_normal(y.size)
+    sl = [rm.get_slit_slices(k) for k in range(12)]
+    np.savez_compressed(os.path.join(HERE, "mrs_blurred.npz"), y=y, adjoint=rm.adjoint(u), u_seed=np.int64(4),
+                        x_seed=np.int64(3),
+                        slit_slices=np.array([[a.start, a.stop, b.start, b.stop] for a, b in sl]),
+                        slit_w=np.array([rm.get_slit_weights(k, sl[k])[0][0] for k in range(12)]))
+
+
 if __name__ == "__main__":
     main()
+    blurred()

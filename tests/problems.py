@@ -82,6 +82,6 @@ def two_channel_small():
                 templates=tpl, sotf=sotf, pointings=[p1, p2], maps=maps, step_deg=STEP_DEG)
 
 
-def oracle_model(cfg, box="fft"):
+def oracle_model(cfg, box="fft", gridding="bilinear"):
     return orc.OracleModel(cfg["sotf"], cfg["templates"], cfg["alpha_axis"], cfg["beta_axis"],
-                           cfg["wavel"], cfg["specs"], cfg["step_deg"], cfg["pointings"], box=box)
+                           cfg["wavel"], cfg["specs"], cfg["step_deg"], cfg["pointings"], box=box, gridding=gridding)

@@ -100,3 +100,20 @@ def test_wslice_excludes_last_plane():
     ifu = make_ifu(orc.ChannelSpec(1e-3, 1e-3, (0, 0), 0, 0.196, 2, 3000.0, np.linspace(7.0, 8.0, 10)))
     ws = ifu.wslice(np.linspace(7.0, 8.0, 24), 0.1)
     assert (ws.start, ws.stop) == (0, 23)        # SURVEY.md 7 hard part 3
+
+
+def test_nn_tables_match_reference_indices():
+    cfg = problems.config1()
+    g = np.load(os.path.join(G, "config1_nn_indices.npz"))
+    spec = cfg["specs"][0]
+    ch = ChannelGeometry(make_ifu(spec), cfg["alpha_axis"], cfg["beta_axis"], cfg["wavel"], 7,
+                         make_pointings(cfg)[0], cfg["step_deg"], gridding="nn_ref")
+    N = 64
+    for p in range(4):
+        i0, i1, y0, y1 = ch.grid_tables(p)
+        assert set(np.unique(y0)) <= {0.0, 1.0} and set(np.unique(y1)) <= {0.0, 1.0}
+        k = (i0 + y0.astype(np.int64)) * N + (i1 + y1.astype(np.int64))       # the single selected pixel, C-order
+        assert np.array_equal(k, g[f"nn_idx_p{p}"].ravel())
+        j0, j1, z0, z1, inside = ch.gridt_tables(p)
+        kt = (j0 + z0.astype(np.int64)) * len(ch.local_beta_axis) + (j1 + z1.astype(np.int64))
+        assert np.array_equal(kt, g[f"nn_idx_t_p{p}"].ravel()) and inside.all()

@@ -159,3 +159,37 @@ def test_lcg_matches_dense_solve():
     # criterion decreases monotonically along the iterates
     c = [orc.crit_val(op, y, orc.lcg(op, y, mu, mur, np.zeros(op.ishape), max_iter=k)["x"], mu, mur) for k in (1, 3, 6)]
     assert c[0] > c[1] > c[2]
+
+
+def test_nn_indices_match_reference_ckdtree():
+    """NN gridding index tables (Channel.precompute_mask recipe) against the reference's cKDTree output."""
+    cfg = problems.config1()
+    g = np.load(os.path.join(G, "config1_nn_indices.npz"))
+    tab = problems.oracle_model(cfg, gridding="nn_ref").channels[0]
+    for p in range(4):
+        assert np.array_equal(tab.nn_idx[p], g[f"nn_idx_p{p}"].ravel())          # integer path: bit-exact
+        assert np.array_equal(tab.nn_idx_t[p], g[f"nn_idx_t_p{p}"].ravel())
+    # the gather the reference performs with these indices reads the alpha/beta-TRANSPOSED pixel
+    cube = np.random.default_rng(0).random((2, 64, 64))
+    tab2 = problems.oracle_model(cfg, gridding="nn").channels[0]
+    assert np.array_equal(orc.gridding(tab, cube, 0), orc.gridding(tab2, cube.transpose(0, 2, 1), 0))
+    om = problems.oracle_model(cfg, box="direct", gridding="nn")
+    assert orc.dottest_gap(om, np.random.default_rng(9)) < 1e-12
+
+
+def test_mrs_blurred_oracle_vs_reference():
+    """BlurredOracle against the reference's MRSBlurred outputs (tests/golden/mrs_blurred.npz)."""
+    g = np.load(os.path.join(G, "mrs_blurred.npz"))
+    N = 96
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    spec = orc.ChannelSpec(1.0 / 3600, 1.2 / 3600, (0.0, 0.0), 0.0, 0.196, 12, 3000.0, np.linspace(7, 8, 10), "R")
+    sotf = orc.ir2fr(orc.gaussian_psf(np.array([7.6]), problems.STEP), (N, N))[0]
+    s = problems.STEP_DEG
+    bo = orc.BlurredOracle(sotf, ax, ax, spec, s, [(0.0, 0.0), (2 * s, -3 * s), (-4 * s, 1 * s)])
+    x = np.random.default_rng(int(g["x_seed"])).random((N, N))
+    u = np.random.default_rng(int(g["u_seed"])).standard_normal(g["y"].size)
+    assert np.array_equal(np.array(bo.slit_slices), g["slit_slices"])
+    assert np.array_equal(np.array([w[0] for w in bo.slit_weights]), g["slit_w"])
+    assert rel(bo.forward(x), g["y"]) < 1e-13 and rel(bo.adjoint(u), g["adjoint"]) < 1e-13
+    v = np.random.default_rng(5).standard_normal(x.shape)
+    assert abs(np.vdot(bo.adjoint(u), v) - np.vdot(u, bo.forward(v))) / abs(np.vdot(u, bo.forward(v))) < 1e-12
