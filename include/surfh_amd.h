@@ -100,6 +100,15 @@ int surfh_adjoint_dev(surfh_plan *plan, const float *y_dev, float *maps_dev);
 int surfh_adjoint_ref_dev(surfh_plan *plan, const float *y_dev, float *maps_dev);
 int surfh_fwadj_dev(surfh_plan *plan, const float *x_dev, float *out_dev);
 
+/* ---- Fourier-domain fused W.C.T operator (Model_WCT, surfh/Models/mixing.py:131-272, di = dj = 1) ----
+ * Uses only the plan's sotf / templates (a plan may be created with n_channels = 0 for this).
+ * cube is [Lc][Na][Nb] (the reference's layout).                                               */
+int surfh_wct_forward(surfh_plan *plan, const float *maps, float *cube);     /* mixing.py:232-245 */
+int surfh_wct_adjoint(surfh_plan *plan, const float *cube, float *maps);     /* mixing.py:247-268 */
+/* explicit normal operator through the per-frequency T x T Hessian sum_l tpl tpl' |H_l|^2
+ * (mixing.py:102-126,177-212,270-272)                                                          */
+int surfh_wct_fwadj(surfh_plan *plan, const float *x, float *out);
+
 /* ---- regularised least squares by linear CG (fusion_CT.py:118-238 + qmm.lcg) ----
  * minimises  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2).
  * grad_norm receives r.r (max_iter+1 doubles), nit the iterations done.             */

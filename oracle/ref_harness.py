@@ -19,6 +19,7 @@ The snapshot is mid-refactor and depends on packages that are not installed
   ``wblur_subSampling(a, w) := python_utils.wblur(a, w).sum(axis=2)``.
 * restated third-party pieces (NOT reference code, flagged in fixture metadata):
     udft.ir2fr   (udft 3.4.0)   -- oracle.surfh_oracle.ir2fr
+    udft.dft2 / idft2 / rdft2 / irdftn -- numpy FFTs with norm="ortho" (only for surfh/Models/mixing.py)
     aljabr.LinOp (aljabr 0.4.0) -- minimal ishape/oshape/matvec/rmatvec holder
 * empty stubs for packages that are imported but unused on the path:
     jax, astropy, loguru, xarray, numba, matplotlib(Agg), einops is real.
@@ -98,7 +99,7 @@ def load():
     sys.path.insert(0, os.path.dirname(HERE))
     from oracle import surfh_oracle as orc
 
-    for name in ("jax", "jax.numpy", "jax.lax", "astropy", "astropy.units", "astropy.coordinates",
+    for name in ("qmm", "surfh.Models.spectro", "surfh.Models.spectrolmm", "jax", "jax.numpy", "jax.lax", "astropy", "astropy.units", "astropy.coordinates",
                  "astropy.io", "astropy.io.fits", "loguru", "xarray", "numba", "progressbar",
                  "SharedArray"):
         if name not in sys.modules:
@@ -111,6 +112,11 @@ def load():
 
     udft = types.ModuleType("udft")
     udft.ir2fr = orc.ir2fr          # restated third-party (udft 3.4.0)
+    # udft's unitary transforms (used only by surfh/Models/mixing.py), restated: numpy FFTs with norm="ortho"
+    udft.dft2 = lambda x: np.fft.fft2(x, norm="ortho")
+    udft.idft2 = lambda x: np.fft.ifft2(x, norm="ortho")
+    udft.rdft2 = lambda x: np.fft.rfft2(x, norm="ortho")
+    udft.irdftn = lambda x, shape: np.fft.irfftn(x, s=tuple(shape), axes=tuple(range(-len(shape), 0)), norm="ortho")
     sys.modules["udft"] = udft
 
     aljabr = types.ModuleType("aljabr")
@@ -184,6 +190,7 @@ def load():
     ns = types.ModuleType("surfh_ref_ns")
     ns.instru, ns.slicer, ns.python_utils, ns.cython_utils = instru, slicer, python_utils, cython_utils
     ns.cythons_files, ns.nn, ns.channel, ns.model, ns.global_variables = cyf, nn, chan, model, gv
+    ns.mixing = lambda: importlib.import_module("surfh.Models.mixing")   # lazy: pulls algorithms.py + shared-memory helpers
     sys.modules["surfh_ref_ns"] = ns
     return ns
 

@@ -781,3 +781,29 @@ class BlurredOracle:
         sf = self.sotf if self.batched else self.sotf[None]
         out = idft(dft(g) * sf.conj(), self.ishape)
         return out if self.batched else out[0]
+
+
+# ----------------------------------------------------------------------------
+# Fourier-domain fused W.C.T operator: Model_WCT (surfh/Models/mixing.py:131-272, di = dj = 1)
+# ----------------------------------------------------------------------------
+class WCTOracle:
+    def __init__(self, psfs_monoch, L_specs, shape_target, L_pce):
+        self.shape = tuple(shape_target)
+        self.specs = np.asarray(L_specs, dtype=np.float64)
+        # H_spec_freq[t, l] = ir2fr(psf[l] pce[l] spec[t, l])   (make_H_spec_freq_sum2, :23-62; kernel_for_sum and
+        # rdft2(decal) are identically 1 for di = dj = 1)
+        self.otf = ir2fr(np.asarray(psfs_monoch) * np.asarray(L_pce)[:, None, None], self.shape)
+        self.ishape = (self.specs.shape[0],) + self.shape
+        self.oshape = (self.specs.shape[1],) + self.shape
+
+    def forward(self, x):                                             # :232-245
+        xf = dft(np.asarray(x, dtype=np.float64))
+        return idft(np.einsum("tl,lij,tij->lij", self.specs, self.otf, xf), self.shape)
+
+    def adjoint(self, y):                                             # :247-268
+        yf = dft(np.asarray(y, dtype=np.float64))
+        return idft(np.einsum("tl,lij,lij->tij", self.specs, self.otf.conj(), yf), self.shape)
+
+    def fwadj(self, x):                                               # :270-272 via the explicit Hessian (:177-212)
+        hth = np.einsum("tl,ul,lij->tuij", self.specs, self.specs, np.abs(self.otf) ** 2)
+        return idft(np.einsum("tuij,uij->tij", hth, dft(np.asarray(x, dtype=np.float64))), self.shape)

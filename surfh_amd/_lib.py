@@ -43,7 +43,8 @@ class Config(C.Structure):
 EXPORTS = [
     "surfh_last_error", "surfh_version", "surfh_plan_create", "surfh_plan_destroy", "surfh_isize", "surfh_osize",
     "surfh_stream", "surfh_forward", "surfh_adjoint", "surfh_adjoint_ref", "surfh_fwadj", "surfh_forward_dev",
-    "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev", "surfh_cg", "surfh_normal_dev",
+    "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev", "surfh_wct_forward", "surfh_wct_adjoint",
+    "surfh_wct_fwadj", "surfh_cg", "surfh_normal_dev",
     "surfh_prior_add_dev", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_residual_dev",
     "surfh_profile_enable", "surfh_profile_count", "surfh_profile_get", "surfh_profile_reset", "surfh_debug_copy",
     "surfh_debug_dims", "surfh_gemm_selftest",
@@ -69,7 +70,8 @@ def load():
     L.surfh_isize.argtypes = [vp]; L.surfh_isize.restype = C.c_int64
     L.surfh_osize.argtypes = [vp]; L.surfh_osize.restype = C.c_int64
     L.surfh_stream.argtypes = [vp]; L.surfh_stream.restype = vp
-    for n in ("surfh_forward", "surfh_adjoint", "surfh_adjoint_ref", "surfh_fwadj"):
+    for n in ("surfh_forward", "surfh_adjoint", "surfh_adjoint_ref", "surfh_fwadj", "surfh_wct_forward", "surfh_wct_adjoint",
+              "surfh_wct_fwadj"):
         getattr(L, n).argtypes = [vp, c_float_p, c_float_p]
     for n in ("surfh_forward_dev", "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev"):
         getattr(L, n).argtypes = [vp, vp, vp]

@@ -14,6 +14,11 @@ int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, cons
 int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj,
                        int T, long PL, int LP);
 
+// hth[(t,t')][k] = sum_l tpl[t,l] tpl[t',l] |sotf[k][l]|^2   (mixing.py:177-203), full T x T stored
+int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP);
+// out[t][c][k] = sum_t' hth[t][t'][k] in[t'][c][k]            (mixing.py:102-126 with di = dj = 1)
+int launch_wct_hess_apply(hipStream_t s, const float *hth, const float *in, float *out, int T, long PL);
+
 // ---- sparse row gather, vectorised over wavelength ----------------------------------------------
 // dst[dst_off[r] + l] (+)= sum_{e<cnt[r]} val[r*W+e] * src[col[r*W+e] + l]   for l in [0, nlam)
 // One workgroup per (row, 1024-wavelength chunk): the table entries are workgroup-uniform (scalar

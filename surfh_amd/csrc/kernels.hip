@@ -111,6 +111,63 @@ __global__ __launch_bounds__(TPB) void specmix_adj_plane_kernel(const float *__r
     *reinterpret_cast<float4 *>(out + (PL + k) * LP + l4) = pi;
 }
 
+// one workgroup per frequency bin: the T x T Hessian block sum_l tpl tpl' |H|^2
+__global__ __launch_bounds__(TPB) void wct_hessian_kernel(const float *__restrict__ sotf, const float *__restrict__ tpl,
+                                                          float *__restrict__ hth, int T, long PL, int LP) {
+    const long k = blockIdx.x;
+    float acc[MAXT * (MAXT + 1) / 2];
+#pragma unroll
+    for (int i = 0; i < MAXT * (MAXT + 1) / 2; ++i) acc[i] = 0.f;
+    for (int l = threadIdx.x; l < LP; l += TPB) {
+        const float hr = sotf[k * LP + l], hi = sotf[(PL + k) * LP + l];
+        const float h2 = hr * hr + hi * hi;
+        float w[MAXT];
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t) w[t] = (t < T) ? tpl[(long)t * LP + l] : 0.f;
+        int i = 0;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+#pragma unroll
+            for (int u = t; u < MAXT; ++u, ++i) acc[i] += w[t] * w[u] * h2;
+    }
+    __shared__ float red[TPB / 64][MAXT * (MAXT + 1) / 2];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < MAXT * (MAXT + 1) / 2; ++i) {
+        float a = acc[i];
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
+        if (lane == 0) red[wv][i] = a;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int i = 0;
+        for (int t = 0; t < MAXT; ++t)
+            for (int u = t; u < MAXT; ++u, ++i) {
+                if (u >= T) continue;
+                float s = 0.f;
+                for (int w = 0; w < TPB / 64; ++w) s += red[w][i];
+                hth[((long)t * T + u) * PL + k] = s;
+                hth[((long)u * T + t) * PL + k] = s;
+            }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void wct_hess_apply_kernel(const float *__restrict__ hth, const float *__restrict__ in,
+                                                             float *__restrict__ out, int T, long PL) {
+    const long k = (long)blockIdx.x * TPB + threadIdx.x;
+    if (k >= PL) return;
+    for (int t = 0; t < T; ++t) {
+        float sr = 0.f, si = 0.f;
+        for (int u = 0; u < T; ++u) {
+            const float h = hth[((long)t * T + u) * PL + k];
+            sr += h * in[((long)u * 2 + 0) * PL + k];
+            si += h * in[((long)u * 2 + 1) * PL + k];
+        }
+        out[((long)t * 2 + 0) * PL + k] = sr;
+        out[((long)t * 2 + 1) * PL + k] = si;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // sparse row gather vectorised over wavelength: one workgroup = one table row x 1024 wavelengths
 // ---------------------------------------------------------------------------------------------
@@ -347,6 +404,17 @@ int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, cons
     } else {
         hipLaunchKernelGGL(specmix_adj_kernel, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
     }
+    return (int)hipGetLastError();
+}
+
+int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP) {
+    if (T < 1 || T > MAXT) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(wct_hessian_kernel, dim3((unsigned)PL), dim3(TPB), 0, s, sotf, tpl, hth, T, PL, LP);
+    return (int)hipGetLastError();
+}
+
+int launch_wct_hess_apply(hipStream_t s, const float *hth, const float *in, float *out, int T, long PL) {
+    hipLaunchKernelGGL(wct_hess_apply_kernel, dim3((unsigned)((PL + TPB - 1) / TPB)), dim3(TPB), 0, s, hth, in, out, T, PL);
     return (int)hipGetLastError();
 }
 

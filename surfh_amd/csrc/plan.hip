@@ -105,7 +105,7 @@ struct surfh_plan {
     float *Cma = nullptr, *Sma = nullptr, *Gc = nullptr, *Gs = nullptr, *Cf = nullptr, *Sf = nullptr;
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
     bool dense_dft = false;
-    float *io_x = nullptr, *io_y = nullptr;
+    float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
     // CG
@@ -737,7 +737,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipSetDevice(p->dev);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
-                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
+                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
         hipFree(v);
     hipFree(p->dscal);
     hipFree(p->dscratch);
@@ -761,7 +761,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     if (!cfg || !out) return fail("null argument");
     *out = nullptr;
     if (cfg->n_alpha < 2 || cfg->n_beta < 2 || cfg->n_lambda < 1) return fail("bad cube shape");
-    if (cfg->n_channels < 1 || !cfg->channels) return fail("at least one channel is required");
+    if (cfg->n_channels < 0 || (cfg->n_channels > 0 && !cfg->channels)) return fail("bad channel list");
+    if (cfg->n_channels == 0 && cfg->n_templates < 1) return fail("a plan without channels needs templates (Model_WCT)");
     if (!cfg->sotf) return fail("sotf is NULL");
     if (cfg->n_templates > 0 && !cfg->templates) return fail("templates is NULL");
     int ndev = 0;
@@ -797,6 +798,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->lo = std::min(p->lo, (int)cfg->channels[i].wslice_start);
         p->hi = std::max(p->hi, (int)cfg->channels[i].wslice_stop);
     }
+    if (cfg->n_channels == 0) { p->lo = 0; p->hi = p->Lc; }
     if (p->lo < 0 || p->hi > p->Lc || p->lo >= p->hi) return bail(fail("channel wslices outside the cube"));
     p->Lown = p->hi - p->lo;
     p->LP = (p->Lown + 127) / 128 * 128;
@@ -954,6 +956,67 @@ int surfh_forward(surfh_plan *p, const float *maps, float *y) { return host_call
 int surfh_adjoint(surfh_plan *p, const float *y, float *maps) { return host_call(p, y, p ? p->osize : 0, maps, p ? p->isize : 0, 1); }
 int surfh_adjoint_ref(surfh_plan *p, const float *y, float *maps) { return host_call(p, y, p ? p->osize : 0, maps, p ? p->isize : 0, 2); }
 int surfh_fwadj(surfh_plan *p, const float *x, float *o) { return host_call(p, x, p ? p->isize : 0, o, p ? p->isize : 0, 3); }
+
+// ---- Model_WCT: the T.C stage alone, cube in the reference's [Lc][Na][Nb] layout ------------------
+static int wct_check(surfh_plan *p) {
+    if (!p) return fail("null plan");
+    if (p->T < 1) return fail("Model_WCT needs templates");
+    if (p->lo != 0 || p->hi != p->Lc) return fail("Model_WCT needs a plan that owns every cube plane");
+    if (hipSetDevice(p->dev) != hipSuccess) return fail("hipSetDevice failed");
+    const size_t n = (size_t)p->Lc * p->Na * p->Nb;
+    if (!p->io_cube && dev_alloc(&p->io_cube, n)) return 1;
+    return 0;
+}
+
+int surfh_wct_forward(surfh_plan *p, const float *maps, float *cube) {
+    if (wct_check(p)) return 1;
+    if (!maps || !cube) return fail("null argument");
+    hipStream_t s = p->stream;
+    HIP_OK(hipMemcpyAsync(p->io_x, maps, p->isize * sizeof(float), hipMemcpyHostToDevice, s));
+    LAUNCH_OK(launch_pad_planes(s, p->io_x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
+    LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP));
+    if (irfft2_cube(p, p->spec, p->cube)) return 1;
+    LAUNCH_OK(launch_cube_from_lam_inner(s, p->cube, p->io_cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP));
+    HIP_OK(hipMemcpyAsync(cube, p->io_cube, (size_t)p->Lc * p->Na * p->Nb * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int surfh_wct_adjoint(surfh_plan *p, const float *cube, float *maps) {
+    if (wct_check(p)) return 1;
+    if (!maps || !cube) return fail("null argument");
+    hipStream_t s = p->stream;
+    HIP_OK(hipMemcpyAsync(p->io_cube, cube, (size_t)p->Lc * p->Na * p->Nb * sizeof(float), hipMemcpyHostToDevice, s));
+    LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
+    LAUNCH_OK(launch_cube_to_lam_inner(s, p->io_cube, p->cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP));
+    if (rfft2_cube(p, p->cube, p->spec)) return 1;
+    LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP));
+    if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
+    LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, p->io_x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    HIP_OK(hipMemcpyAsync(maps, p->io_x, p->isize * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int surfh_wct_fwadj(surfh_plan *p, const float *x, float *out) {
+    if (wct_check(p)) return 1;
+    if (!x || !out) return fail("null argument");
+    hipStream_t s = p->stream;
+    if (!p->hth) {
+        if (dev_alloc(&p->hth, (size_t)p->T * p->T * p->PL) || dev_alloc(&p->mhat2, (size_t)p->T * 2 * p->PL)) return 1;
+        LAUNCH_OK(launch_wct_hessian(s, p->sotf, p->tpl, p->hth, p->T, p->PL, p->LP));
+    }
+    HIP_OK(hipMemcpyAsync(p->io_x, x, p->isize * sizeof(float), hipMemcpyHostToDevice, s));
+    LAUNCH_OK(launch_pad_planes(s, p->io_x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
+    LAUNCH_OK(launch_wct_hess_apply(s, p->hth, p->mhat, p->mhat2, p->T, p->PL));
+    if (irfft2_planes(p, p->mhat2, p->maps_pad, p->T)) return 1;
+    LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, p->io_x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    HIP_OK(hipMemcpyAsync(out, p->io_x, p->isize * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+}
 
 // ---- CG building blocks ---------------------------------------------------------------------
 int surfh_normal_dev(surfh_plan *p, const float *d, float *q, double mu) {

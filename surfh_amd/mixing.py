@@ -1,0 +1,69 @@
+"""``Model_WCT``: the reference's Fourier-domain fused "W.C.T" operator
+(surfh/Models/mixing.py:131-272, with its decimation di = dj = 1) on the HIP library.
+
+    forward : cube[l] = irfft2( sum_t H[t,l] rfft2(maps[t]) ),  H[t,l] = spec[t,l] pce[l] ir2fr(psf[l])
+    adjoint : maps[t] = irfft2( sum_l conj(H[t,l]) rfft2(cube[l]) )
+    fwadj   : A^T A through the per-frequency T x T Hessian  sum_l spec[t,l] spec[t',l] |pce[l] otf[l]|^2
+
+``H`` is never materialised (the reference holds a [T, L, N, N/2+1] complex128 array, mixing.py:40):
+the products are formed on the fly from the OTF and the spectra.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .linop import LinOp
+from .synth import ir2fr
+
+
+class Model_WCT(LinOp):
+    def __init__(self, psfs_monoch, L_specs, shape_target, L_pce, *, device: int = 0):
+        psfs_monoch = np.asarray(psfs_monoch, dtype=np.float64)
+        L_specs = np.ascontiguousarray(L_specs, dtype=np.float64)
+        L_pce = np.asarray(L_pce, dtype=np.float64)
+        assert psfs_monoch.shape[1] <= shape_target[0] and psfs_monoch.shape[2] <= shape_target[1]   # mixing.py:135-136
+        self.di = self.dj = 1
+        self.shape_target = tuple(int(v) for v in shape_target)
+        self.n_spec, self.n_lamb = L_specs.shape
+        sotf = np.ascontiguousarray(ir2fr(psfs_monoch * L_pce[:, None, None], self.shape_target), dtype=np.complex128)
+        super().__init__(ishape=(self.n_spec,) + self.shape_target, oshape=(self.n_lamb,) + self.shape_target)
+        cfg = _lib.Config()
+        cfg.n_alpha, cfg.n_beta, cfg.n_lambda, cfg.n_templates = self.shape_target[0], self.shape_target[1], self.n_lamb, self.n_spec
+        cfg.templates = _lib.dptr(L_specs)
+        cfg.sotf = sotf.view(np.float64).ctypes.data_as(_lib.c_double_p)
+        cfg.n_channels, cfg.channels = 0, None
+        cfg.device, cfg.stream, cfg.split_k_forward = device, None, 0
+        L = _lib.load()
+        plan = C.c_void_p()
+        _lib.check(L.surfh_plan_create(C.byref(cfg), C.byref(plan)), ValueError)
+        self._L, self._plan = L, plan
+
+    def close(self):
+        if getattr(self, "_plan", None):
+            self._L.surfh_plan_destroy(self._plan)
+            self._plan = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _call(self, fn, x, shape_in, shape_out):
+        assert tuple(np.shape(x)) == tuple(shape_in)          # mixing.py:233,248,271
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+        out = np.empty(int(np.prod(shape_out)), dtype=np.float32)
+        _lib.check(fn(self._plan, _lib.fptr(a), _lib.fptr(out)))
+        return out.astype(np.float64).reshape(shape_out)
+
+    def forward(self, x):
+        return self._call(self._L.surfh_wct_forward, x, self.ishape, self.oshape)
+
+    def adjoint(self, y):
+        return self._call(self._L.surfh_wct_adjoint, y, self.oshape, self.ishape)
+
+    def fwadj(self, x):
+        return self._call(self._L.surfh_wct_fwadj, x, self.ishape, self.ishape)

@@ -209,6 +209,28 @@ def blurred():
                         slit_w=np.array([rm.get_slit_weights(k, sl[k])[0][0] for k in range(12)]))
 
 
+def wct_inputs():
+    orc = problems.orc
+    rng = np.random.default_rng(11)
+    L, T, shape = 24, 3, (40, 36)
+    psfs = orc.gaussian_psf(np.linspace(7, 8, L), 0.025)[:, 12:29, 12:29]
+    psfs = psfs / psfs.sum(axis=(1, 2), keepdims=True)
+    specs = rng.random((T, L)) + 0.5
+    pce = rng.random(L) + 0.5
+    x = rng.random((T,) + shape)
+    y = rng.standard_normal((L,) + shape)
+    return psfs, specs, shape, pce, x, y
+
+
+def wct():
+    """Model_WCT (surfh/Models/mixing.py:131-272): forward, adjoint and the explicit-Hessian fwadj."""
+    ns = rh.load()
+    psfs, specs, shape, pce, x, y = wct_inputs()
+    rm = ns.mixing().Model_WCT(psfs, specs, shape, pce)
+    np.savez_compressed(os.path.join(HERE, "model_wct.npz"), forward=rm.forward(x), adjoint=rm.adjoint(y), fwadj=rm.fwadj(x))
+
+
 if __name__ == "__main__":
     main()
     blurred()
+    wct()

@@ -78,3 +78,20 @@ def test_mrs_blurred_batched_over_wavelength():
     assert m.forward(x).shape == (40, 3 * 12 * 6)
     assert max(e.values()) < TOL
     m.close()
+
+
+def test_model_wct_vs_reference():
+    """Fourier-domain fused W.C.T operator (mixing.py:131-272) against the reference's own outputs."""
+    from surfh_amd.mixing import Model_WCT
+    src = open(os.path.join(G, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("def wct_inputs"):src.index("def wct():")], {"problems": problems, "np": np}, ns)
+    psfs, specs, shape, pce, x, y = ns["wct_inputs"]()
+    g = np.load(os.path.join(G, "model_wct.npz"))
+    m = Model_WCT(psfs, specs, shape, pce)
+    assert m.ishape == (3, 40, 36) and m.oshape == (24, 40, 36)
+    e = dict(fwd=rel(m.forward(x), g["forward"]), adj=rel(m.adjoint(y), g["adjoint"]), fwadj=rel(m.fwadj(x), g["fwadj"]))
+    print(e)
+    assert max(e.values()) < TOL
+    assert rel(m.fwadj(x), m.adjoint(m.forward(x))) < 1e-5
+    m.close()

@@ -193,3 +193,19 @@ def test_mrs_blurred_oracle_vs_reference():
     assert rel(bo.forward(x), g["y"]) < 1e-13 and rel(bo.adjoint(u), g["adjoint"]) < 1e-13
     v = np.random.default_rng(5).standard_normal(x.shape)
     assert abs(np.vdot(bo.adjoint(u), v) - np.vdot(u, bo.forward(v))) / abs(np.vdot(u, bo.forward(v))) < 1e-12
+
+
+def test_model_wct_oracle_vs_reference():
+    """WCTOracle against the reference's Model_WCT outputs (tests/golden/model_wct.npz)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(G, "make_golden.py"))
+    # only the seeded inputs are taken from the generator module (its reference import is lazy)
+    src = open(os.path.join(G, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("def wct_inputs"):src.index("def wct():")], {"problems": problems, "np": np}, ns)
+    psfs, specs, shape, pce, x, y = ns["wct_inputs"]()
+    g = np.load(os.path.join(G, "model_wct.npz"))
+    wo = orc.WCTOracle(psfs, specs, shape, pce)
+    assert rel(wo.forward(x), g["forward"]) < 1e-13
+    assert rel(wo.adjoint(y), g["adjoint"]) < 1e-13
+    assert rel(wo.fwadj(x), g["fwadj"]) < 1e-13
