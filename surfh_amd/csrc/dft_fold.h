@@ -34,3 +34,26 @@ struct DftFoldArgs {
 };
 
 int launch_dft_fold(hipStream_t stream, const DftFoldArgs &g);
+
+// Complex-to-complex pass with all four folded products in one workgroup (the spectrum is read once):
+//   P1 = Cm*fold+(Xr)  P2 = Sm*fold-(Xi)  P3 = Sm*fold-(Xr)  P4 = Cm*fold+(Xi)
+//   dst_r[r] = P1 - sgn*P2   dst_r[Rn-r] = P1 + sgn*P2   dst_i[r] = P4 + sgn*P3   dst_i[Rn-r] = P4 - sgn*P3
+// sgn = +1: inverse transform (e^{+i}), sgn = -1: forward transform (e^{-i}).
+struct DftFold4Args {
+    const float *Cm = nullptr, *Sm = nullptr;   // [MP][KP]
+    int lda = 0;
+    const float *src_r = nullptr, *src_i = nullptr;
+    long ldb = 0, sB = 0;
+    float *dst_r = nullptr, *dst_i = nullptr;
+    long ldc = 0, sC = 0;
+    float sgn = 1.f;
+    int Nn = 0;          // transform length (same on both sides)
+    int rvalid = 0;      // Nn/2 + 1
+    int MP = 0, KP = 0, N = 0, batch = 1;
+    // optional fused spectral mix on the source (forward model only): src = H * sum_t tpl[t][l] * mhat[t][k][kb]
+    // with the column index n = kb * LP + l  (mhat == nullptr: plain source)
+    const float *mhat = nullptr, *tpl = nullptr;
+    int T = 0, LP = 0;
+    long PL = 0, KBP = 0;
+};
+int launch_dft_fold4(hipStream_t stream, const DftFold4Args &g);

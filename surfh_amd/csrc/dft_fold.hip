@@ -123,7 +123,165 @@ __global__ __launch_bounds__(256) void dft_fold_kernel(DftFoldArgs g) {
         }
 }
 
+// ---- four-product variant for the complex-to-complex passes ------------------------------------------
+constexpr int BN4 = 64;
+constexpr int A4_FLOATS = BM * ASTR;        // one A tile
+constexpr int B4_FLOATS = BK * BN4;         // one folded B tile
+constexpr int BUF4_FLOATS = 2 * A4_FLOATS + 4 * B4_FLOATS;
+
+__global__ __launch_bounds__(256, 2) void dft_fold4_kernel(DftFold4Args g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN4;
+    const int ar = tid >> 2, ac = (tid & 3) * 4;       // A tiles: 128 rows x 16 k
+    const int br = tid >> 4, bc = (tid & 15) * 4;      // B tiles: 16 k x 64 cols
+    const long b = blockIdx.z;
+    const float *Xr = g.src_r + b * g.sB, *Xi = g.src_i + b * g.sB;
+    const int nk = g.KP / BK;
+    const int kin = g.Nn / 2 + 1;
+
+    // fused spectral mix: the column tile lies inside one k_beta (LP is a multiple of the tile width)
+    const bool mix = g.mhat != nullptr;
+    const int kb = mix ? n0 / g.LP : 0;
+    const int l0 = mix ? n0 % g.LP : 0;
+
+    f32x16 P1[2], P2[2], P3[2], P4[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) P1[i][r] = P2[i][r] = P3[i][r] = P4[i][r] = 0.f;
+
+    float4 rc0, rc1, rs0, rs1, bre, bro, bie, bio;
+
+    // X = H * S with S = sum_t tpl[t][l] * mhat[t][k][kb] when the spectral mix is fused, else the plain row
+#define F4_LOAD_ROW(k_, vr_, vi_)                                                                           \
+    {                                                                                                       \
+        vr_ = *reinterpret_cast<const float4 *>(Xr + (long)(k_) * g.ldb + n0 + bc);                         \
+        vi_ = *reinterpret_cast<const float4 *>(Xi + (long)(k_) * g.ldb + n0 + bc);                         \
+        if (mix) {                                                                                          \
+            float4 sr = make_float4(0.f, 0.f, 0.f, 0.f), si = sr;                                           \
+            for (int t = 0; t < g.T; ++t) {                                                                 \
+                const float4 w = *reinterpret_cast<const float4 *>(g.tpl + (long)t * g.LP + l0 + bc);       \
+                const float mr = g.mhat[((long)t * 2 + 0) * g.PL + (long)(k_) * g.KBP + kb];                \
+                const float mi = g.mhat[((long)t * 2 + 1) * g.PL + (long)(k_) * g.KBP + kb];                \
+                sr.x += w.x * mr; sr.y += w.y * mr; sr.z += w.z * mr; sr.w += w.w * mr;                     \
+                si.x += w.x * mi; si.y += w.y * mi; si.z += w.z * mi; si.w += w.w * mi;                     \
+            }                                                                                               \
+            const float4 hr = vr_, hi = vi_;                                                                \
+            vr_.x = hr.x * sr.x - hi.x * si.x; vi_.x = hr.x * si.x + hi.x * sr.x;                           \
+            vr_.y = hr.y * sr.y - hi.y * si.y; vi_.y = hr.y * si.y + hi.y * sr.y;                           \
+            vr_.z = hr.z * sr.z - hi.z * si.z; vi_.z = hr.z * si.z + hi.z * sr.z;                           \
+            vr_.w = hr.w * sr.w - hi.w * si.w; vi_.w = hr.w * si.w + hi.w * sr.w;                           \
+        }                                                                                                   \
+    }
+#define F4_GLOAD(kt_)                                                                                       \
+    {                                                                                                       \
+        const int k0 = (kt_) * BK;                                                                          \
+        rc0 = *reinterpret_cast<const float4 *>(g.Cm + (long)(m0 + ar) * g.lda + k0 + ac);                  \
+        rc1 = *reinterpret_cast<const float4 *>(g.Cm + (long)(m0 + ar + 64) * g.lda + k0 + ac);             \
+        rs0 = *reinterpret_cast<const float4 *>(g.Sm + (long)(m0 + ar) * g.lda + k0 + ac);                  \
+        rs1 = *reinterpret_cast<const float4 *>(g.Sm + (long)(m0 + ar + 64) * g.lda + k0 + ac);             \
+        const int k = k0 + br;                                                                              \
+        float4 xr, xi;                                                                                      \
+        F4_LOAD_ROW(k, xr, xi);                                                                             \
+        bre = xr; bie = xi;                                                                                 \
+        /* k = 0 (and the Nyquist row of an even length) has no partner: the odd folds vanish */           \
+        bro = make_float4(0.f, 0.f, 0.f, 0.f); bio = bro;                                                   \
+        if ((k >= 1) && (k < kin) && (2 * k != g.Nn)) {                                                     \
+            float4 qr, qi;                                                                                  \
+            F4_LOAD_ROW(g.Nn - k, qr, qi);                                                                  \
+            bre.x += qr.x; bre.y += qr.y; bre.z += qr.z; bre.w += qr.w;                                     \
+            bro.x = xr.x - qr.x; bro.y = xr.y - qr.y; bro.z = xr.z - qr.z; bro.w = xr.w - qr.w;             \
+            bie.x += qi.x; bie.y += qi.y; bie.z += qi.z; bie.w += qi.w;                                     \
+            bio.x = xi.x - qi.x; bio.y = xi.y - qi.y; bio.z = xi.z - qi.z; bio.w = xi.w - qi.w;             \
+        }                                                                                                   \
+    }
+#define F4_LSTORE(buf_)                                                                                     \
+    {                                                                                                       \
+        float *base = lds + (buf_) * BUF4_FLOATS;                                                           \
+        *reinterpret_cast<float4 *>(base + ar * ASTR + ac) = rc0;                                           \
+        *reinterpret_cast<float4 *>(base + (ar + 64) * ASTR + ac) = rc1;                                    \
+        *reinterpret_cast<float4 *>(base + A4_FLOATS + ar * ASTR + ac) = rs0;                               \
+        *reinterpret_cast<float4 *>(base + A4_FLOATS + (ar + 64) * ASTR + ac) = rs1;                        \
+        float *bb = base + 2 * A4_FLOATS + br * BN4 + bc;                                                   \
+        *reinterpret_cast<float4 *>(bb) = bre;                                                              \
+        *reinterpret_cast<float4 *>(bb + B4_FLOATS) = bro;                                                  \
+        *reinterpret_cast<float4 *>(bb + 2 * B4_FLOATS) = bie;                                              \
+        *reinterpret_cast<float4 *>(bb + 3 * B4_FLOATS) = bio;                                              \
+    }
+
+    F4_GLOAD(0);
+    F4_LSTORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        F4_GLOAD((kt + 1 < nk) ? kt + 1 : kt);
+        const float *Ac = lds + buf * BUF4_FLOATS, *As_ = Ac + A4_FLOATS, *Bb = Ac + 2 * A4_FLOATS;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 c4[2], s4[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                c4[mt] = *reinterpret_cast<const float4 *>(Ac + (wm * 64 + mt * 32 + l31) * ASTR + 8 * q + 4 * h);
+                s4[mt] = *reinterpret_cast<const float4 *>(As_ + (wm * 64 + mt * 32 + l31) * ASTR + 8 * q + 4 * h);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int off = (8 * q + 4 * h + m) * BN4 + wn * 32 + l31;
+                const float vre = Bb[off], vro = Bb[B4_FLOATS + off], vie = Bb[2 * B4_FLOATS + off], vio = Bb[3 * B4_FLOATS + off];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float cv = (m == 0) ? c4[mt].x : (m == 1) ? c4[mt].y : (m == 2) ? c4[mt].z : c4[mt].w;
+                    const float sv = (m == 0) ? s4[mt].x : (m == 1) ? s4[mt].y : (m == 2) ? s4[mt].z : s4[mt].w;
+                    P1[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cv, vre, P1[mt], 0, 0, 0);
+                    P2[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, vio, P2[mt], 0, 0, 0);
+                    P3[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(sv, vro, P3[mt], 0, 0, 0);
+                    P4[mt] = __builtin_amdgcn_mfma_f32_32x32x2f32(cv, vie, P4[mt], 0, 0, 0);
+                }
+            }
+        }
+        F4_LSTORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef F4_LOAD_ROW
+#undef F4_GLOAD
+#undef F4_LSTORE
+
+    float *dr = g.dst_r + b * g.sC, *di = g.dst_i + b * g.sC;
+    const int col = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (row >= g.rvalid) continue;
+            const float p1 = P1[mt][r], p2 = g.sgn * P2[mt][r], p3 = g.sgn * P3[mt][r], p4 = P4[mt][r];
+            dr[(long)row * g.ldc + col] = p1 - p2;
+            di[(long)row * g.ldc + col] = p4 + p3;
+            if (row >= 1 && 2 * row != g.Nn) {
+                dr[(long)(g.Nn - row) * g.ldc + col] = p1 + p2;
+                di[(long)(g.Nn - row) * g.ldc + col] = p4 - p3;
+            }
+        }
+}
+
 }  // namespace
+
+int launch_dft_fold4(hipStream_t stream, const DftFold4Args &g) {
+    if (g.MP % BM || g.KP % BK || g.N % BN4 || g.batch < 1) return (int)hipErrorInvalidValue;
+    if (g.mhat && (g.LP % BN4 || g.T < 1)) return (int)hipErrorInvalidValue;
+    const size_t lds_bytes = (size_t)2 * BUF4_FLOATS * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)dft_fold4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    dim3 grid(g.N / BN4, g.MP / BM, g.batch);
+    hipLaunchKernelGGL(dft_fold4_kernel, grid, dim3(256), lds_bytes, stream, g);
+    return (int)hipGetLastError();
+}
 
 int launch_dft_fold(hipStream_t stream, const DftFoldArgs &g) {
     if (g.MP % BM || g.KP % BK || g.N % BN || g.batch < 1) return (int)hipErrorInvalidValue;

@@ -27,3 +27,8 @@ struct GemmArgs {
 
 // returns hipError_t as int; name is used by the profiler
 int launch_gemm_f32(hipStream_t stream, const GemmArgs &g);
+
+// C[M][N] = A[M][K] * B[N][K]^T on the bf16 matrix cores with exact 3-way operand splitting (fp32-accurate,
+// see gemm_bf16x3.hip).  B0/ldb describe B as [N][K]; M, N multiples of 128.
+int launch_gemm_nt_bf16x3(hipStream_t stream, const GemmArgs &g);
+

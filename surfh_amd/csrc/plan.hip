@@ -104,7 +104,7 @@ struct surfh_plan {
     // folded-DFT matrices [MPx][KPx]: cos/sin along alpha; weighted cos/sin for c2r; plain cos/sin for r2c
     float *Cma = nullptr, *Sma = nullptr, *Gc = nullptr, *Gs = nullptr, *Cf = nullptr, *Sf = nullptr;
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
-    bool dense_dft = false;
+    bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
@@ -245,10 +245,11 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     c->shift = (c->ws0 - p->lo) - c->ws0a;
     c->LinA = (c->ws1 - p->lo) - c->ws0a;
     c->LinP = pad64(c->LinA);
+    if (!c->bsum && ((long)c->nbs * c->LinP) % 128) c->LinP += 64;    // K, NP, LdetP multiples of 128: tile grid of the GEMMs
     c->nlam = (c->LinA + 3) / 4 * 4;
     c->K = (c->bsum ? 1 : c->nbs) * c->LinP;
-    c->NP = pad64(c->P * c->S * c->aout);
-    c->LdetP = pad64(c->Ldet);
+    c->NP = (c->P * c->S * c->aout + 127) / 128 * 128;
+    c->LdetP = (c->Ldet + 127) / 128 * 128;
     c->ysize = (long)c->P * c->S * c->Ldet * c->aout;
 
     const long nloc = (long)c->na * c->nb;
@@ -378,12 +379,12 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
 }
 
 int pick_split(const Channel &c, int forced) {
-    if (forced > 0) return (c.K % (16 * forced) == 0) ? forced : 1;
+    if (forced > 0) return (c.K % (32 * forced) == 0) ? forced : 1;
     const int bm = (c.NP % 128 == 0) ? 128 : 64, bn = (c.LdetP % 128 == 0) ? 128 : 64;
     const long tiles = (long)(c.NP / bm) * (c.LdetP / bn);
     int best = 1;
     for (int s : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
-        if (c.K % (16 * s)) continue;
+        if (c.K % (32 * s)) continue;
         if (c.K / s < 256) break;
         best = s;
         if (tiles * s >= 768) break;
@@ -551,6 +552,16 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
         Prof pr(p, "dft_fold_rows_fwd");
         LAUNCH_OK(launch_dft_fold(p->stream, g));
     }
+    if (!p->fold2) {   // c2c along alpha, all four folded products in one workgroup, batched over k_beta
+        DftFold4Args h;
+        h.Cm = p->Cma; h.Sm = p->Sma; h.lda = p->KPa;
+        h.src_r = p->ycol; h.src_i = p->ycol + (long)p->KBP * p->NAP * LP; h.ldb = LP; h.sB = p->NAP * LP;
+        h.dst_r = dst; h.dst_i = dst + p->PL * LP; h.ldc = p->KBP * LP; h.sC = LP;
+        h.sgn = -1.f; h.Nn = p->Na; h.rvalid = ha; h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
+        Prof pr(p, "dft_fold_cols_fwd");
+        LAUNCH_OK(launch_dft_fold4(p->stream, h));
+        return 0;
+    }
     for (int z = 0; z < 2; ++z) {   // c2c along alpha, one launch per output component, batched over k_beta
         DftFoldArgs h;
         h.A[0] = z ? p->Sma : p->Cma; h.A[1] = z ? p->Cma : p->Sma; h.lda = p->KPa;
@@ -567,9 +578,19 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
     return 0;
 }
 
-int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
+int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = false) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    if (!p->fold2) {   // c2c along alpha; with `mix` the source spectrum is formed on the fly as sotf * sum_t tpl * mhat
+        DftFold4Args g;
+        g.Cm = p->Cma; g.Sm = p->Sma; g.lda = p->KPa;
+        g.src_r = src; g.src_i = src + p->PL * LP; g.ldb = p->KBP * LP;
+        g.dst_r = p->ycol; g.dst_i = p->ycol + (long)p->NAP * p->KBP * LP; g.ldc = p->KBP * LP;
+        g.sgn = 1.f; g.Nn = p->Na; g.rvalid = ha; g.MP = p->MPa; g.KP = p->KPa; g.N = (int)(hb * LP);
+        if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = p->LP; g.PL = p->PL; g.KBP = p->KBP; }
+        Prof pr(p, mix ? "dft_fold_cols_inv_mix" : "dft_fold_cols_inv");
+        LAUNCH_OK(launch_dft_fold4(p->stream, g));
+    } else
     for (int z = 0; z < 2; ++z) {   // c2c along alpha
         DftFoldArgs g;
         g.A[0] = z ? p->Sma : p->Cma; g.A[1] = z ? p->Cma : p->Sma; g.lda = p->KPa;
@@ -600,7 +621,7 @@ int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
 // pipelines on device buffers
 // ---------------------------------------------------------------------------------------------
 int rfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? rfft2_lam(p, src, dst) : rfft2_lam_fold(p, src, dst); }
-int irfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_fold(p, src, dst); }
+int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false) { return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_fold(p, src, dst, mix); }
 
 int forward_dev(surfh_plan *p, const float *x, float *y) {
     hipStream_t s = p->stream;
@@ -617,11 +638,16 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
         }
         if (rfft2_cube(p, p->cube, p->mhat)) return 1;
     }
-    {
-        Prof pr(p, "specmix_fwd");
-        LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP));
+    if (p->T > 0 && p->fuse_mix && !p->dense_dft && !p->fold2) {
+        // spectral mix x OTF fused into the loader of the first inverse pass: `spec` is never written
+        if (irfft2_cube(p, p->sotf, p->cube, true)) return 1;
+    } else {
+        {
+            Prof pr(p, "specmix_fwd");
+            LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP));
+        }
+        if (irfft2_cube(p, p->spec, p->cube)) return 1;
     }
-    if (irfft2_cube(p, p->spec, p->cube)) return 1;
     for (auto &c : p->ch) {
         {
             Prof pr(p, "spmm_gather_fwd");
@@ -632,14 +658,19 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             LAUNCH_OK(launch_cube_from_lam_inner(s, c.Xs + c.shift, y + c.yoff, 0, c.Lin, 1, c.P * c.S * c.aout, 1, c.LinP));
             continue;
         }
-        GemmArgs g;   // y^T[n][l'] = Xs[n][k] Wt[k][l']
+        GemmArgs g;   // y^T[n][l'] = sum_k Xs[n][k] W[l'][k]
         g.A0 = c.Xs; g.lda = c.K;
-        g.B0 = c.Wt; g.ldb = c.LdetP;
         g.C = c.Cpart; g.ldc = c.LdetP;
         g.M = c.NP; g.N = c.LdetP; g.K = c.K; g.splitK = c.splitK; g.sCsplit = (long)c.NP * c.LdetP;
         {
             Prof pr(p, "gemm_wblur_fwd");
-            LAUNCH_OK(launch_gemm_f32(s, g));
+            if (p->wblur_fp32) {
+                g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [K][N]
+                LAUNCH_OK(launch_gemm_f32(s, g));
+            } else {
+                g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
+                LAUNCH_OK(launch_gemm_nt_bf16x3(s, g));
+            }
         }
         {
             Prof pr(p, "y_from_cpart");
@@ -671,14 +702,19 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             Prof pr(p, "ymat_from_y");
             LAUNCH_OK(launch_ymat_from_y(s, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP));
         }
-        GemmArgs g;   // Xs_t[n][k] = y^T[n][l'] W[l'][k]
+        GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
         g.A0 = c.ymat; g.lda = c.LdetP;
-        g.B0 = c.W; g.ldb = c.K;
         g.C = c.Xs; g.ldc = c.K;
         g.M = c.NP; g.N = c.K; g.K = c.LdetP;
         {
             Prof pr(p, "gemm_wblur_adj");
-            LAUNCH_OK(launch_gemm_f32(s, g));
+            if (p->wblur_fp32) {
+                g.B0 = c.W; g.ldb = c.K;             // B as [K'=l'][N'=k]
+                LAUNCH_OK(launch_gemm_f32(s, g));
+            } else {
+                g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
+                LAUNCH_OK(launch_gemm_nt_bf16x3(s, g));
+            }
         }
         {
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
@@ -843,6 +879,12 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     {   // folded-DFT matrices
         const char *e = getenv("SURFH_DFT_DENSE");
         p->dense_dft = e && e[0] == '1';
+        const char *e2 = getenv("SURFH_FOLD2");
+        p->fold2 = e2 && e2[0] == '1';            // two-launch c2c passes (A/B reference for the fused four-product kernel)
+        const char *e3 = getenv("SURFH_NO_FUSED_MIX");
+        p->fuse_mix = !(e3 && e3[0] == '1');
+        const char *e4 = getenv("SURFH_WBLUR_FP32");
+        p->wblur_fp32 = e4 && e4[0] == '1';       // R / R^T on the fp32-input MFMA instead of the split-bf16 path
         const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
         p->MPa = (ha + 127) / 128 * 128; p->KPa = (ha + 15) / 16 * 16;
         p->MPb = (hb + 127) / 128 * 128; p->KPb = (hb + 15) / 16 * 16;
@@ -1171,7 +1213,7 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
         if (info) {                                 // (LinP, first valid lambda column, n_beta_slit, Lin)
             dims[0] = p->ch[c].LinP; dims[1] = p->ch[c].shift; dims[2] = p->ch[c].nbs; dims[3] = p->ch[c].Lin;
         } else {                                    // [(p,s,a)][b'][LinP]
-            *ptr = p->ch[c].Xs; dims[0] = p->ch[c].NP; dims[1] = p->ch[c].nbs; dims[2] = p->ch[c].LinP;
+            *ptr = p->ch[c].Xs; dims[0] = p->ch[c].NP; dims[1] = p->ch[c].bsum ? 1 : p->ch[c].nbs; dims[2] = p->ch[c].LinP;
         }
     } else if (w == "info") {
         dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->ch.empty() ? 0 : p->ch[0].splitK; dims[3] = p->ch.empty() ? 0 : p->ch[0].adjT.t.W;
@@ -1216,7 +1258,19 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
     GemmArgs g;
     g.A0 = dA; g.lda = K; g.B0 = dB; g.ldb = N; g.C = dC; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.splitK = sk; g.sCsplit = (long)M * N;
-    int rc = launch_gemm_f32(nullptr, g);
+    int rc;
+    const char *mode = getenv("SURFH_SELFTEST_BF16X3");
+    if (mode && mode[0] == '1') {
+        // NT form: B is handed over as [K][N]; transpose it on the host into [N][K]
+        std::vector<float> bt((size_t)N * K);
+        for (int k = 0; k < K; ++k)
+            for (int n = 0; n < N; ++n) bt[(size_t)n * K + k] = B[(size_t)k * N + n];
+        HIP_OK(hipMemcpy(dB, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
+        g.ldb = K;
+        rc = launch_gemm_nt_bf16x3(nullptr, g);
+    } else {
+        rc = launch_gemm_f32(nullptr, g);
+    }
     if (rc == 0) rc = (int)hipDeviceSynchronize();
     std::vector<float> h((size_t)sk * M * N);
     if (rc == 0) rc = (int)hipMemcpy(h.data(), dC, h.size() * 4, hipMemcpyDeviceToHost);

@@ -47,6 +47,26 @@ def test_gemm_mfma_selftest():
         assert e < 2e-6, (M, N, K, sk, e)
 
 
+def test_gemm_split_bf16_selftest():
+    """Exact 3-way bf16 splitting on the bf16 matrix cores must be as accurate as the fp32 MFMA path."""
+    from surfh_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(1)
+    os.environ["SURFH_SELFTEST_BF16X3"] = "1"
+    try:
+        for (M, N, K, sk) in [(128, 128, 16, 1), (256, 128, 256, 1), (128, 384, 1024, 2)]:
+            A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, K)))).astype(np.float32)   # wide dynamic range
+            B = rng.standard_normal((K, N)).astype(np.float32) + np.arange(N, dtype=np.float32)[None, :] * 0.02
+            Cg = np.empty((M, N), dtype=np.float32)
+            _lib.check(L.surfh_gemm_selftest(0, M, N, K, sk, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
+            Cr = A.astype(np.float64) @ B.astype(np.float64)
+            e = rel(Cg, Cr)
+            note("gemm_bf16x3", M=M, N=N, K=K, sk=sk, err=e)
+            assert e < 5e-7, (M, N, K, sk, e)
+    finally:
+        os.environ.pop("SURFH_SELFTEST_BF16X3")
+
+
 @pytest.fixture(scope="module")
 def c1():
     cfg = problems.config1()
