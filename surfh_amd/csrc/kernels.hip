@@ -173,9 +173,12 @@ __global__ __launch_bounds__(TPB) void wct_hess_apply_kernel(const float *__rest
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float *__restrict__ src,
                                                         float *__restrict__ dst, int nlam, int accumulate) {
-    const int r = blockIdx.x;
+    // workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD one
+    // contiguous band of table rows, so neighbouring rows -- which share most of their taps -- hit the same L2
+    const int per = (t.R + 7) / 8;
+    const int r = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     const int l4 = (blockIdx.y * TPB + threadIdx.x) * 4;
-    if (l4 >= nlam) return;
+    if (r >= t.R || l4 >= nlam) return;
     const int n = t.cnt[r];
     const int64_t *col = t.col + (long)r * t.W;
     const float *val = t.val + (long)r * t.W;
@@ -421,7 +424,7 @@ int launch_wct_hess_apply(hipStream_t s, const float *hth, const float *in, floa
 int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate) {
     if (t.R == 0 || nlam <= 0) return 0;
     if (nlam % 4) return (int)hipErrorInvalidValue;
-    dim3 grid(t.R, (nlam / 4 + TPB - 1) / TPB);
+    dim3 grid((t.R + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
     hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate);
     return (int)hipGetLastError();
 }
