@@ -134,13 +134,15 @@ def main():
         el = float(t.item())
 
     if rank == 0:
+        for name, (cnt, ms) in sorted(prof.items(), key=lambda kv: -kv[1][1]):
+            log(f"[prof] {name:28s} launches {cnt:5d}  avg {ms / max(cnt, 1):8.4f} ms  per-step {ms / args.steps:8.4f} ms")
         N = len(prob["alpha_axis"])
         Nf = N * (N // 2 + 1)
         info = m.debug_buffer("info")
         Lown = int(info[1] - info[0])
         groups = {}
         for name, (cnt, ms) in prof.items():
-            g = "dft_pass" if (name.startswith("gemm_dft_") and not name.endswith("_maps")) or name.startswith("dft_fold_") else \
+            g = "dft_pass" if (name.startswith("gemm_dft_") and not name.endswith("_maps")) or name.startswith("dft_fold_") or name.startswith("dft_x3_") else \
                 "gemm_wblur" if name.startswith("gemm_wblur") else name
             a = groups.setdefault(g, [0, 0.0])
             a[0] += cnt

@@ -297,7 +297,8 @@ def _fov_weight(fovb, sl, la, lb):
 
 
 def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_degree,
-                  pointings: Sequence[Tuple[float, float]], with_grid=True, gridding="bilinear") -> ChannelTables:
+                  pointings: Sequence[Tuple[float, float]], with_grid=True, gridding="bilinear",
+                  lam_slice=None) -> ChannelTables:
     """Everything Channel.__init__ / Slicer derive (spectroModelChannel.py:27-108)."""
     srf = get_srf(spec.det_pix_size, step_degree * 3600)               # spectroModel.py:67-70
     origin_pix = (pix(spec.origin[0], step_degree), pix(spec.origin[1], step_degree))   # IFU.pix
@@ -327,6 +328,12 @@ def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_deg
     wpsf = spectral_psf(spec.grating_resolution, spec.wavel_axis,
                         beta_in_slit - np.mean(beta_in_slit), wavel_axis[ws[0]:ws[1]],
                         scale=(spec.wavel_axis[1] - spec.wavel_axis[0]) / spec.det_pix_size)
+    if lam_slice is not None:      # one of n contiguous parts of the window (the parts' outputs add up)
+        i, n = lam_slice
+        lin = ws[1] - ws[0]
+        a, b = (lin * i) // n, (lin * (i + 1)) // n
+        wpsf = wpsf[:, a:b, :]
+        ws = (ws[0] + a, ws[0] + b)
 
     tab = ChannelTables(spec=spec, srf=srf, origin_pix=origin_pix, pointings=pts, wslice=ws,
                         local_alpha_axis=la, local_beta_axis=lb,
@@ -522,7 +529,8 @@ class OracleModel:
     """spectroSigRLSCT (spectroModel.py:39-185) in float64."""
 
     def __init__(self, sotf, templates, alpha_axis, beta_axis, wavelength_axis,
-                 specs: Sequence[ChannelSpec], step_degree, pointings, box="fft", gridding="bilinear"):
+                 specs: Sequence[ChannelSpec], step_degree, pointings, box="fft", gridding="bilinear",
+                 lam_slices=None):
         self.sotf = np.asarray(sotf)
         self.templates = None if templates is None else np.asarray(templates, dtype=np.float64)
         self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
@@ -530,7 +538,9 @@ class OracleModel:
         self.wavelength_axis = np.asarray(wavelength_axis, dtype=np.float64)
         self.box = box
         self.channels = [build_channel(sp, self.alpha_axis, self.beta_axis, self.wavelength_axis,
-                                       step_degree, pointings[k], gridding=gridding) for k, sp in enumerate(specs)]
+                                       step_degree, pointings[k], gridding=gridding,
+                                       lam_slice=None if lam_slices is None else lam_slices[k])
+                         for k, sp in enumerate(specs)]
         n_lead = self.templates.shape[0] if self.templates is not None else len(self.wavelength_axis)
         self.ishape = (n_lead, len(self.alpha_axis), len(self.beta_axis))
         self.cube_shape = (len(self.wavelength_axis), len(self.alpha_axis), len(self.beta_axis))

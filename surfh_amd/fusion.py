@@ -85,6 +85,34 @@ def band_cost(n_pix: int, geo) -> float:
     return r + fft
 
 
+def partition_lambda(costs: Sequence[float], world: int) -> List[List[Tuple[int, Tuple[int, int]]]]:
+    """Assign (band, lambda part (i, n)) units to ranks.  world <= bands: whole bands ((0, 1) parts) by
+    longest-processing-time greedy; world > bands: every band gets n_k >= 1 ranks (the costliest bands get the
+    extra ones) and its wavelength window is cut into n_k contiguous parts.  The R contraction runs over
+    lambda, so the parts' outputs ADD: the ranks of a band all-reduce their partial y (one extra, group-local
+    collective), while the FFT-conv stage, the gather and the GEMM K range are all divided by n_k."""
+    nb = len(costs)
+    out: List[List[Tuple[int, Tuple[int, int]]]] = [[] for _ in range(world)]
+    if world <= nb:
+        load = [0.0] * world
+        for k in sorted(range(nb), key=lambda i: -costs[i]):
+            r = int(np.argmin(load))
+            out[r].append((k, (0, 1)))
+            load[r] += costs[k]
+        for r in range(world):
+            out[r].sort()
+        return out
+    share = [1] * nb
+    for _ in range(world - nb):
+        share[int(np.argmax([costs[i] / share[i] for i in range(nb)]))] += 1
+    r = 0
+    for k in range(nb):
+        for i in range(share[k]):
+            out[r].append((k, (i, share[k])))
+            r += 1
+    return out
+
+
 def partition_units(costs: Sequence[float], n_pointings: Sequence[int], world: int) -> List[List[Tuple[int, List[int]]]]:
     """Assign (band, pointing subset) units to ranks.  world <= bands: whole bands, longest-processing-time
     greedy; world > bands: every band gets >= 1 ranks (the costliest bands get the extra ones) and its
@@ -117,9 +145,12 @@ class DistributedFusion:
     """One rank of the channel-sharded CG.  ``prob`` is a dict as produced by ``surfh_amd.synth.problem``."""
 
     def __init__(self, prob: dict, rank: int = 0, world: int = 1, device: int = 0, with_ref: bool = False,
-                 model_factory=None):
-        """``model_factory(ifus, pointings)`` replaces the HIP operator (used by the world_size-2 gloo
-        tests on CPU, where a checker-backed stand-in exposes the same ``*_dev`` methods on CPU tensors)."""
+                 model_factory=None, split: str = "lambda"):
+        """``model_factory(ifus, pointings, lam_slices)`` replaces the HIP operator (used by the gloo tests on
+        CPU, where a checker-backed stand-in exposes the same ``*_dev`` methods on CPU tensors).
+        ``split``: how a band is shared when there are more ranks than bands -- "lambda" (its wavelength
+        window, partial y all-reduced inside the band's group) or "pointing" (its pointings, no extra
+        collective but the band's FFT-conv work is repeated on every rank of the group)."""
         import contextlib
         import torch
         self.torch = torch
@@ -132,10 +163,27 @@ class DistributedFusion:
         geos = [ChannelGeometry(i, prob["alpha_axis"], prob["beta_axis"], prob["wavel"], s, p, prob["step_deg"])
                 for i, s, p in zip(ifus, srfs, pts)]
         self.costs = [band_cost(n_pix, g) for g in geos]
-        self.assignment = partition_units(self.costs, [len(p) for p in pts], world)
-        self.units = self.assignment[rank]
-        my_ifus = [ifus[k] for k, _ in self.units]
-        my_pts = [instru.CoordList([pts[k][i] for i in sel]) for k, sel in self.units]
+        self.group = None
+        if split == "lambda":
+            self.assignment = partition_lambda(self.costs, world)
+            self.units = self.assignment[rank]
+            my_ifus = [ifus[k] for k, _ in self.units]
+            my_pts = [pts[k] for k, _ in self.units]
+            my_slices = [None if n == 1 else (i, n) for _, (i, n) in self.units]
+            # one process group per shared band; every rank creates every group, in the same order
+            if world > len(ifus):
+                for k in range(len(ifus)):
+                    members = [r for r in range(world) if any(kk == k for kk, _ in self.assignment[r])]
+                    if len(members) > 1:
+                        grp = torch.distributed.new_group(ranks=members)
+                        if rank in members:
+                            self.group = grp
+        else:
+            self.assignment = partition_units(self.costs, [len(p) for p in pts], world)
+            self.units = self.assignment[rank]
+            my_ifus = [ifus[k] for k, _ in self.units]
+            my_pts = [instru.CoordList([pts[k][i] for i in sel]) for k, sel in self.units]
+            my_slices = None
         if model_factory is None:
             torch.cuda.set_device(device)
             self.tstream = torch.cuda.Stream(device=device)
@@ -144,14 +192,15 @@ class DistributedFusion:
             self._sync = self.tstream.synchronize
             self.model = spectroSigRLSCT(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"],
                                          prob["wavel"], my_ifus, prob["step_deg"], my_pts, device=device,
-                                         with_ref=with_ref, stream=self.tstream.cuda_stream)
+                                         with_ref=with_ref, stream=self.tstream.cuda_stream, lam_slices=my_slices)
         else:
             self.tstream = None
             self.dev = "cpu"
             self._ctx = contextlib.nullcontext
             self._sync = lambda: None
-            self.model = model_factory(my_ifus, my_pts)
+            self.model = model_factory(my_ifus, my_pts, my_slices)
         self.n = self.model.isize
+        self._ytmp = None
 
     def _allreduce(self, t):
         if self.world > 1:
@@ -164,15 +213,27 @@ class DistributedFusion:
             x = torch.as_tensor(np.ascontiguousarray(maps, dtype=np.float32), device=self.dev)
             y = torch.empty(self.model.osize, dtype=torch.float32, device=x.device)
             self.model.forward_dev(x, y)
+            if self.group is not None:              # lambda parts of one band: the partial outputs add up
+                torch.distributed.all_reduce(y, group=self.group)
             if noise_rel:
-                g = torch.Generator(device=x.device).manual_seed(seed + self.rank)
+                # the ranks sharing a band must draw the same noise: seed by the band, not by the rank
+                g = torch.Generator(device=x.device).manual_seed(seed + (self.units[0][0] if self.group is not None else self.rank))
                 y += torch.randn(y.shape, generator=g, device=x.device, dtype=torch.float32) * (noise_rel * y.square().mean().sqrt())
         self._sync()
         return y
 
     def normal(self, d, q, mu, mu_reg):
         """q = mu A^T A d (summed over ranks) + mu_reg (Dr^T Dr + Dc^T Dc) d."""
-        self.model.normal_dev(d, q, mu)
+        if self.group is None:
+            self.model.normal_dev(d, q, mu)
+        else:                                       # y = sum over the band's lambda parts, then each part's A^T
+            if self._ytmp is None:
+                self._ytmp = self.torch.empty(self.model.osize, dtype=self.torch.float32, device=d.device)
+            self.model.forward_dev(d, self._ytmp)
+            self.torch.distributed.all_reduce(self._ytmp, group=self.group)
+            self.model.adjoint_dev(self._ytmp, q)
+            if mu != 1.0:
+                q *= mu
         self._allreduce(q)
         if mu_reg:
             self.model.prior_add_dev(d, q, mu_reg)

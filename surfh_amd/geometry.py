@@ -145,7 +145,10 @@ class ChannelGeometry:
     """Host description of one channel (spectroModelChannel.py:27-108), no arithmetic on cubes."""
 
     def __init__(self, instr: instru.IFU, alpha_axis, beta_axis, wavel_axis, srf: int,
-                 pointings: instru.CoordList, step_degree: float, gridding: str = "bilinear"):
+                 pointings: instru.CoordList, step_degree: float, gridding: str = "bilinear",
+                 lam_slice=None):
+        """``lam_slice = (i, n)`` keeps only the i-th of n contiguous parts of the channel's wavelength window
+        (multi-GPU: a band's lambda range shared by n ranks; the partial outputs add up to the band's output)."""
         if gridding not in ("bilinear", "nn", "nn_ref"):
             raise ValueError("gridding must be 'bilinear', 'nn' or 'nn_ref'")
         self.gridding_mode = gridding
@@ -161,6 +164,14 @@ class ChannelGeometry:
         self.slicer = Slicer(self.instr, self.global_wavelength_axis, self.alpha_axis, self.beta_axis,
                              self.local_alpha_axis, self.local_beta_axis, srf)
         self.wslice = self.instr.wslice(self.global_wavelength_axis, 0.1)
+        self.band_wslice = self.wslice
+        self.lam_slice = lam_slice
+        if lam_slice is not None:
+            i, n = lam_slice
+            ws0, lin = self.wslice.start, self.wslice.stop - self.wslice.start
+            if not (0 <= i < n <= lin):
+                raise ValueError(f"bad lam_slice {lam_slice} for a window of {lin} planes")
+            self.wslice = slice(ws0 + (lin * i) // n, ws0 + (lin * (i + 1)) // n)
         n_out = ceil(self.slicer.npix_slit_alpha_width / srf)
         self.oshape = (len(self.pointings), self.instr.n_slit, len(self.instr.wavel_axis), n_out)
         self.slices_shape = (len(self.pointings), self.instr.n_slit, n_out)
@@ -181,9 +192,12 @@ class ChannelGeometry:
         if self._wpsf is None:
             n = self.slicer.npix_slit_beta_width
             b = np.arange(0, n) * self.beta_step
-            self._wpsf = self.instr.spectral_psf(
-                b - np.mean(b), self.global_wavelength_axis[self.wslice],
+            # always evaluated on the band's full window (its normalisation runs over that axis), then cut
+            full = self.instr.spectral_psf(
+                b - np.mean(b), self.global_wavelength_axis[self.band_wslice],
                 arcsec2micron=self.instr.wavel_step / self.instr.det_pix_size, type="mrs")
+            o = self.wslice.start - self.band_wslice.start
+            self._wpsf = np.ascontiguousarray(full[:, o: o + (self.wslice.stop - self.wslice.start), :])
         return self._wpsf
 
     def grid_tables(self, p: int):

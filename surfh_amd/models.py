@@ -34,7 +34,7 @@ class spectroSigRLSCT(LinOp):
     def __init__(self, sotf, templates, alpha_axis, beta_axis, wavelength_axis, instrs: List[instru.IFU],
                  step_degree: float, pointings: Sequence[instru.CoordList], *, device: int = 0,
                  channels: Optional[Sequence[int]] = None, with_ref: bool = True, stream: Optional[int] = None,
-                 split_k_forward: int = 0, gridding: str = "bilinear"):
+                 split_k_forward: int = 0, gridding: str = "bilinear", lam_slices=None):
         self.sotf = sotf
         self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
         self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
@@ -47,7 +47,8 @@ class spectroSigRLSCT(LinOp):
         self.srfs = instru.get_srf([i.det_pix_size for i in instrs], step_degree * 3600)
         # every channel's geometry is known to every rank; `channels` selects the ones this plan owns
         self.all_channels = [ChannelGeometry(ins, self.alpha_axis, self.beta_axis, self.wavelength_axis, srf,
-                                             pointings[k], step_degree, gridding=gridding)
+                                             pointings[k], step_degree, gridding=gridding,
+                                             lam_slice=None if lam_slices is None else lam_slices[k])
                              for k, (srf, ins) in enumerate(zip(self.srfs, instrs))]
         self.owned = list(range(len(instrs))) if channels is None else [int(c) for c in channels]
         self.channels = [self.all_channels[k] for k in self.owned]

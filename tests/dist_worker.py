@@ -22,12 +22,12 @@ from surfh_amd.fusion import DistributedFusion  # noqa: E402
 class OracleBackedModel:
     """CPU stand-in exposing the device-pointer API of spectroSigRLSCT on CPU torch tensors."""
 
-    def __init__(self, prob, ifus, pts):
+    def __init__(self, prob, ifus, pts, lam_slices=None):
         specs = [orc.ChannelSpec(i.fov.alpha_width, i.fov.beta_width, (i.fov.origin.alpha, i.fov.origin.beta), i.fov.angle,
                                  i.det_pix_size, i.n_slit, i.w_blur.grating_resolution, i.wavel_axis, i.name) for i in ifus]
         p = [[(c.alpha, c.beta) for c in pl] for pl in pts]
         self.om = orc.OracleModel(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"], prob["wavel"],
-                                  specs, prob["step_deg"], p, box="direct")
+                                  specs, prob["step_deg"], p, box="direct", lam_slices=lam_slices)
         self.ishape, self.isize, self.osize = self.om.ishape, self.om.isize, self.om.osize
 
     @staticmethod
@@ -81,7 +81,8 @@ def main():
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     dist.init_process_group("gloo", rank=rank, world_size=world)
     prob = small_problem()
-    fus = DistributedFusion(prob, rank=rank, world=world, model_factory=lambda i, p: OracleBackedModel(prob, i, p))
+    fus = DistributedFusion(prob, rank=rank, world=world, split=os.environ.get("DIST_SPLIT", "lambda"),
+                            model_factory=lambda i, p, ls: OracleBackedModel(prob, i, p, ls))
     y = fus.make_data(prob["maps"], noise_rel=0.0)
     res = fus.lcg(y, mu=1.0, mu_reg=50.0, max_iter=6, tol=1e-14)
     # every rank must hold the same replicated iterate
@@ -90,7 +91,7 @@ def main():
     same = all(torch.equal(xs[0], t) for t in xs)
     if rank == 0:
         np.savez(os.environ["DIST_OUT"], x=res.x, grad_norm=np.array(res.grad_norm), same=same,
-                 units=np.array([len(u) for u in fus.assignment]))
+                 units=np.array([len(u) for u in fus.assignment]), has_group=fus.group is not None)
     dist.barrier()
     dist.destroy_process_group()
 

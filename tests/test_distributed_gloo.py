@@ -9,17 +9,19 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world", [2, 3])
-def test_sharded_cg_matches_single_process(tmp_path, world):
+@pytest.mark.parametrize("world,split", [(2, "lambda"), (3, "lambda"), (4, "lambda"), (3, "pointing")])
+def test_sharded_cg_matches_single_process(tmp_path, world, split):
     out = str(tmp_path / "dist.npz")
-    env = dict(os.environ, DIST_OUT=out, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
+    env = dict(os.environ, DIST_OUT=out, DIST_SPLIT=split, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2")
     port = 29500 + os.getpid() % 400 + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py")]
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
     got = np.load(out)
     assert bool(got["same"])                      # x is replicated bit-identically on every rank
-    assert list(got["units"]) == ([1, 1] if world == 2 else [1, 1, 1])   # 2 bands; the 3rd rank gets a pointing half
+    assert list(got["units"]) == [1] * world                # 2 bands; extra ranks share a band (lambda parts / pointings)
+    if split == "pointing" or world == 2:
+        assert not bool(got["has_group"])           # no group-local collective in these layouts
 
     # single-process reference: the checker's lcg on the full (unsharded) operator
     sys.path.insert(0, os.path.join(ROOT, "tests"))
