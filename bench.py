@@ -140,36 +140,54 @@ def main():
         Nf = N * (N // 2 + 1)
         info = m.debug_buffer("info")
         Lown = int(info[1] - info[0])
+        # HIP-event names -> kernel symbols as rocprofv3 reports them (profiles/*_kernel_stats_*.csv)
+        def symbol(name):
+            if name.startswith("gemm_wblur"):
+                return "gemm_nt_bf16x3_kernel" if os.environ.get("SURFH_WBLUR_FP32") != "1" else "gemm_f32_kernel<128, 128>"
+            if name.startswith("dft_fold_cols"):
+                return "dft_fold4_kernel"
+            if name.startswith("dft_fold_rows"):
+                return "dft_fold_kernel"
+            if name.startswith("spmm_"):
+                return "spmm_rows_kernel"
+            if name.startswith("gemm_dft_") and name.endswith("_maps"):
+                return "gemm_f32_kernel<64, 64>"
+            return name + "_kernel"
         groups = {}
         for name, (cnt, ms) in prof.items():
-            g = "dft_pass" if (name.startswith("gemm_dft_") and not name.endswith("_maps")) or name.startswith("dft_fold_") or name.startswith("dft_x3_") else \
-                "gemm_wblur" if name.startswith("gemm_wblur") else name
-            a = groups.setdefault(g, [0, 0.0])
+            a = groups.setdefault(symbol(name), [0, 0.0])
             a[0] += cnt
             a[1] += ms
         roof = None
         stage_ms = {k: round(v[1] / args.steps, 4) for k, v in sorted(groups.items(), key=lambda kv: -kv[1][1])}
+        traffic_file = os.path.join(ROOT, "profiles", f"r01_final_pmc_traffic_config{args.config}.json")
+        pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
         if groups:
             dom = max(groups, key=lambda k: groups[k][1])
             cnt, ms = groups[dom]
-            if dom == "gemm_wblur":
-                flops = sum(2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
-                            for c in m.channels)   # per launch, averaged over the fwd/adj launches of all channels
-                per_launch = flops / max(1, len(m.channels)) * 1.0
-                ach = per_launch / (ms / cnt * 1e-3) / 1e12
+            avg_s = ms / cnt * 1e-3
+            per_step = cnt / max(1, args.steps)
+            traffic = pmc.get(dom, {}).get("hbm_bytes_per_launch")
+            if dom.startswith("gemm_nt") or dom.startswith("gemm_f32_kernel<128"):
+                # R and R^T: 2 * P*S*Ldet*alpha_out * Lin*n_beta flops per channel and direction (SURVEY.md 8d F_iter)
+                flops_step = sum(2.0 * 2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
+                                 for c in m.channels)
+                ach = flops_step / per_step / avg_s / 1e12
                 roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TF, "traffic": None, "kernel": "gemm_f32_kernel (R / R^T)",
-                        "launches": cnt, "avg_ms": ms / cnt}
+                        "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "kernel": dom, "launches": cnt,
+                        "avg_ms": ms / cnt,
+                        "note": "algorithmic fp32 flops of R/R^T priced against the fp32-input MFMA peak (the dtype the path "
+                                "computes in); the kernel evaluates each fp32 product as 6 bf16 MFMA products (exact 3-way "
+                                "split), i.e. it sustains 6x this rate on the bf16 matrix cores",
+                        "bf16_matrix_core_tflops": 6.0 * ach, "bf16_peak_frac": 6.0 * ach / 2500.0}
             else:
-                # FFT-conv stage: one 2-D transform over the owned planes algorithmically moves
-                # Lown*(Nf*8 + N^2*4) bytes; a CG step holds two such transforms (one per
-                # direction), each made of cnt/steps/2 launches of this kernel.
-                per_step = cnt / max(1, args.steps)
-                bytes_launch = 2.0 * Lown * (Nf * 8 + N * N * 4) / per_step if dom == "dft_pass" else 0.0
-                ach = bytes_launch / (ms / cnt * 1e-3) / 1e9
+                # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
+                # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel
+                # (complex pass) and one of dft_fold_kernel (real pass): half of a transform's bytes per launch.
+                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith("dft_fold") else None
+                ach = bytes_launch / avg_s / 1e9 if bytes_launch else None
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": f"{dom} (1-D DFT passes of the FFT-conv stage over {Lown} planes)" if dom == "dft_pass" else dom,
+                        "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic, "kernel": dom,
                         "launches": cnt, "avg_ms": ms / cnt}
         out = {
             "metric": "CG-iterations/sec (forward+adjoint) on 251x251x4000 cube" if args.config == "3"
