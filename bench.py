@@ -88,10 +88,18 @@ def main():
         log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    # rehearsal on a one-GPU box: SURFH_REHEARSAL=1 puts every rank on device 0 and uses gloo for the
+    # collectives (RCCL refuses two ranks on one device); the production path is nccl (= RCCL), one rank per GPU
+    rehearsal = os.environ.get("SURFH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
 
     from surfh_amd import synth
     from surfh_amd.fusion import DistributedFusion
@@ -129,7 +137,7 @@ def main():
         prof = m.profile()
         m.profile_enable(False)
     if world > 1:
-        t = torch.tensor([el], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([el], dtype=torch.float64, device="cpu" if rehearsal else f"cuda:{local}")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
@@ -139,7 +147,7 @@ def main():
         N = len(prob["alpha_axis"])
         Nf = N * (N // 2 + 1)
         info = m.debug_buffer("info")
-        Lown = int(info[1] - info[0])
+        Lown = int(info[2])      # planes this rank stores (union of its channels' windows)
         # HIP-event names -> kernel symbols as rocprofv3 reports them (profiles/*_kernel_stats_*.csv)
         def symbol(name):
             if name.startswith("gemm_wblur"):

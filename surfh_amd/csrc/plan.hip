@@ -98,6 +98,14 @@ struct surfh_plan {
     int Na = 0, Nb = 0, Lc = 0, T = 0, NAP = 0, NBP = 0, KAP = 0, KBP = 0;
     long PL = 0, PLc = 0;
     int lo = 0, hi = 0, Lown = 0, LP = 0;
+    // owned cube planes = union of the channels' windows, stored compactly: segment = (first plane, length, compact offset)
+    struct Seg { int start, len, coff; };
+    std::vector<Seg> segs;
+    std::vector<int> planes;   // compact index -> cube plane
+    int compact(int l) const {
+        for (auto &g : segs) if (l >= g.start && l <= g.start + g.len) return g.coff + (l - g.start);
+        return -1;
+    }
     float *sotf = nullptr, *tpl = nullptr, *mhat = nullptr, *spec = nullptr, *ycol = nullptr, *cube = nullptr,
           *maps_pad = nullptr, *ycol_maps = nullptr;
     float *Fi = nullptr, *Gi = nullptr, *Gf = nullptr, *Ff = nullptr, *GiT = nullptr, *GfT = nullptr;
@@ -241,9 +249,11 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     for (int s = 0; s < c->S; ++s)
         if (d.slit_beta0[s] < 0 || d.slit_beta0[s] + c->nbs > c->nb) return fail("slit %d beta window outside the local grid", s);
     // wavelength window inside the plan's planes, start aligned to 4 floats for 16-byte vector access
-    c->ws0a = ((c->ws0 - p->lo) / 4) * 4;
-    c->shift = (c->ws0 - p->lo) - c->ws0a;
-    c->LinA = (c->ws1 - p->lo) - c->ws0a;
+    const int cw0 = p->compact(c->ws0);
+    if (cw0 < 0) return fail("channel window not inside the plan's planes");
+    c->ws0a = (cw0 / 4) * 4;
+    c->shift = cw0 - c->ws0a;
+    c->LinA = (cw0 + c->Lin) - c->ws0a;
     c->LinP = pad64(c->LinA);
     if (!c->bsum && ((long)c->nbs * c->LinP) % 128) c->LinP += 64;    // K, NP, LdetP multiples of 128: tile grid of the GEMMs
     c->nlam = (c->LinA + 3) / 4 * 4;
@@ -634,7 +644,8 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
     } else {
         {
             Prof pr(p, "cube_transpose");
-            LAUNCH_OK(launch_cube_to_lam_inner(s, x, p->cube, p->lo, p->Lown, p->Na, p->Nb, p->NAP, p->LP));
+            for (auto &g : p->segs)
+                LAUNCH_OK(launch_cube_to_lam_inner(s, x, p->cube + g.coff, g.start, g.len, p->Na, p->Nb, p->NAP, p->LP));
         }
         if (rfft2_cube(p, p->cube, p->mhat)) return 1;
     }
@@ -733,10 +744,10 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
     } else {
         if (irfft2_cube(p, p->mhat, p->cube)) return 1;
         const long pl = (long)p->Na * p->Nb;
-        if (p->lo > 0) LAUNCH_OK(launch_fill_zero(s, x, (long)p->lo * pl));
-        if (p->hi < p->Lc) LAUNCH_OK(launch_fill_zero(s, x + (long)p->hi * pl, (long)(p->Lc - p->hi) * pl));
+        if (p->Lown < p->Lc) LAUNCH_OK(launch_fill_zero(s, x, (long)p->Lc * pl));   // planes no channel observes
         Prof pr(p, "cube_transpose");
-        LAUNCH_OK(launch_cube_from_lam_inner(s, p->cube, x, p->lo, p->Lown, p->Na, p->Nb, p->NAP, p->LP));
+        for (auto &g : p->segs)
+            LAUNCH_OK(launch_cube_from_lam_inner(s, p->cube + g.coff, x, g.start, g.len, p->Na, p->Nb, p->NAP, p->LP));
     }
     return 0;
 }
@@ -836,7 +847,31 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     }
     if (cfg->n_channels == 0) { p->lo = 0; p->hi = p->Lc; }
     if (p->lo < 0 || p->hi > p->Lc || p->lo >= p->hi) return bail(fail("channel wslices outside the cube"));
-    p->Lown = p->hi - p->lo;
+    {   // merge the channel windows into disjoint segments; the plan stores only those planes
+        std::vector<std::pair<int, int>> iv;
+        if (cfg->n_channels == 0) iv.push_back({0, p->Lc});
+        for (int i = 0; i < cfg->n_channels; ++i) iv.push_back({cfg->channels[i].wslice_start, cfg->channels[i].wslice_stop});
+        std::sort(iv.begin(), iv.end());
+        int coff = 0;
+        for (auto &v : iv) {
+            if (v.first >= v.second) return bail(fail("empty channel window"));
+            if (!p->segs.empty() && v.first <= p->segs.back().start + p->segs.back().len) {
+                auto &g = p->segs.back();
+                const int grow = std::max(0, v.second - (g.start + g.len));
+                g.len += grow;
+                coff += grow;
+            } else {
+                // every segment starts on a multiple of 4 compact planes (16-byte vector access per channel window)
+                coff = (coff + 3) / 4 * 4;
+                p->segs.push_back({v.first, v.second - v.first, coff});
+                coff += v.second - v.first;
+            }
+        }
+        p->Lown = coff;
+        p->planes.assign(p->Lown, -1);
+        for (auto &g : p->segs)
+            for (int l = 0; l < g.len; ++l) p->planes[g.coff + l] = g.start + l;
+    }
     p->LP = (p->Lown + 127) / 128 * 128;
     p->isize = (long)(p->T > 0 ? p->T : p->Lc) * p->Na * p->Nb;
     const size_t LP = (size_t)p->LP;
@@ -851,7 +886,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         for (int a = 0; a < p->Na; ++a) {
             std::fill(row.begin(), row.end(), 0.f);
             for (int l = 0; l < p->Lown; ++l) {
-                const double *src = cfg->sotf + ((size_t)(p->lo + l) * p->Na + a) * nkb * 2;
+                if (p->planes[l] < 0) continue;     // alignment gap between segments: stays zero
+                const double *src = cfg->sotf + ((size_t)p->planes[l] * p->Na + a) * nkb * 2;
                 for (int k = 0; k < nkb; ++k) {
                     row[(size_t)k * LP + l] = (float)src[2 * k];
                     row[((size_t)p->KBP + k) * LP + l] = (float)src[2 * k + 1];
@@ -866,7 +902,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     if (p->T > 0) {
         std::vector<float> t((size_t)p->T * LP, 0.f);
         for (int k = 0; k < p->T; ++k)
-            for (int l = 0; l < p->Lown; ++l) t[(size_t)k * LP + l] = (float)cfg->templates[(size_t)k * p->Lc + p->lo + l];
+            for (int l = 0; l < p->Lown; ++l)
+                if (p->planes[l] >= 0) t[(size_t)k * LP + l] = (float)cfg->templates[(size_t)k * p->Lc + p->planes[l]];
         if (dev_upload(&p->tpl, t)) return bail(1);
     }
     {
@@ -1003,7 +1040,7 @@ int surfh_fwadj(surfh_plan *p, const float *x, float *o) { return host_call(p, x
 static int wct_check(surfh_plan *p) {
     if (!p) return fail("null plan");
     if (p->T < 1) return fail("Model_WCT needs templates");
-    if (p->lo != 0 || p->hi != p->Lc) return fail("Model_WCT needs a plan that owns every cube plane");
+    if (p->segs.size() != 1 || p->segs[0].start != 0 || p->segs[0].len != p->Lc) return fail("Model_WCT needs a plan that owns every cube plane");
     if (hipSetDevice(p->dev) != hipSuccess) return fail("hipSetDevice failed");
     const size_t n = (size_t)p->Lc * p->Na * p->Nb;
     if (!p->io_cube && dev_alloc(&p->io_cube, n)) return 1;
@@ -1216,7 +1253,7 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
             *ptr = p->ch[c].Xs; dims[0] = p->ch[c].NP; dims[1] = p->ch[c].bsum ? 1 : p->ch[c].nbs; dims[2] = p->ch[c].LinP;
         }
     } else if (w == "info") {
-        dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->ch.empty() ? 0 : p->ch[0].splitK; dims[3] = p->ch.empty() ? 0 : p->ch[0].adjT.t.W;
+        dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->Lown; dims[3] = (int64_t)p->segs.size();
     } else {
         return fail("unknown debug buffer '%s'", w.c_str());
     }

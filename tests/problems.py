@@ -82,6 +82,22 @@ def two_channel_small():
                 templates=tpl, sotf=sotf, pointings=[p1, p2], maps=maps, step_deg=STEP_DEG)
 
 
+def two_channel_disjoint():
+    """Two channels whose wavelength windows do NOT touch: the plan stores two plane segments with a gap."""
+    N, Lc = 48, 160
+    ax = orc.synthetic_axes(N, STEP_DEG)
+    wav = np.linspace(7.20, 8.45, Lc)
+    s1 = orc.ChannelSpec(0.6 / 3600, 0.7 / 3600, (0.0, 0.0), 8.2, 0.196, 3, 3050.0, np.linspace(7.32, 7.42, 30), "A")
+    s2 = orc.ChannelSpec(0.7 / 3600, 0.6 / 3600, (0.0, 0.0), -5.0, 0.196, 2, 2900.0, np.linspace(8.15, 8.30, 34), "B")
+    tpl = orc.synthetic_templates(Lc)
+    sotf = orc.ir2fr(orc.gaussian_psf(wav, STEP), (N, N))
+    p1 = orc.dither4(s1.det_pix_size, s1.beta_width / s1.n_slit)[:2]
+    p2 = orc.dither4(s2.det_pix_size, s2.beta_width / s2.n_slit)[:3]
+    maps = np.random.default_rng(8).random((4, N, N))
+    return dict(N=N, Lc=Lc, alpha_axis=ax, beta_axis=ax.copy(), wavel=wav, specs=[s1, s2],
+                templates=tpl, sotf=sotf, pointings=[p1, p2], maps=maps, step_deg=STEP_DEG)
+
+
 def oracle_model(cfg, box="fft", gridding="bilinear"):
     return orc.OracleModel(cfg["sotf"], cfg["templates"], cfg["alpha_axis"], cfg["beta_axis"],
                            cfg["wavel"], cfg["specs"], cfg["step_deg"], cfg["pointings"], box=box, gridding=gridding)

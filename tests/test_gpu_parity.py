@@ -260,3 +260,42 @@ def test_device_pointer_api_and_profile(c1):
     assert all(ms >= 0 for _, ms in prof.values())
     n = om.isize
     assert abs(m.dot_dev(x, x, n) - float(np.sum(cfg["maps"].astype(np.float32).astype(np.float64) ** 2))) < 1e-6 * n
+
+
+def test_quad_criterion_mirror(c1):
+    """QuadCriterion_MRS.run_method('lcg') / get_crit_val (surfh/Simulation/fusion_CT.py:66-265) on the device CG."""
+    from surfh_amd.fusion import QuadCriterion_MRS
+    cfg, om, m = c1
+    y = om.forward(cfg["maps"])
+    crit = QuadCriterion_MRS(1.0, y, m, 5e3, printing=False, gradient="separated")
+    res = crit.run_method("lcg", maximum_iterations=8, tolerance=1e-12, value_init=0.5)
+    assert res.x.shape == (om.isize,) and res.nit == 8 and len(res.grad_norm) == 9
+    ref = orc.lcg(om, y, 1.0, 5e3, np.ones(om.ishape) * 0.5, tol=1e-12, max_iter=8)
+    assert rel(res.x.reshape(om.ishape), ref["x"]) < 5e-3
+    c_gpu = crit.get_crit_val(res.x)
+    c_ref = orc.crit_val(om, y, ref["x"], 1.0, 5e3)
+    c_init = orc.crit_val(om, y, np.ones(om.ishape) * 0.5, 1.0, 5e3)
+    assert abs(c_gpu - c_ref) / c_ref < 1e-2 and c_gpu < c_init
+    with pytest.raises(NotImplementedError):
+        crit.run_method("mmmg")
+
+
+@pytest.mark.parametrize("lmm", [True, False])
+def test_disjoint_wavelength_windows(lmm):
+    """A plan stores only the union of its channels' windows; here that union has a gap."""
+    cfg = dict(problems.two_channel_disjoint())
+    if not lmm:
+        cfg["templates"] = None
+    om = problems.oracle_model(cfg, box="direct")
+    w = [c.wslice for c in om.channels]
+    assert w[0][1] < w[1][0]                                    # really disjoint
+    m = build_model(cfg)
+    info = m.debug_buffer("info")
+    assert int(info[3]) == 2 and int(info[2]) < w[1][1] - w[0][0]     # two segments, fewer planes than the span
+    x = cfg["maps"] if lmm else np.random.default_rng(5).random(om.ishape)
+    u = np.random.default_rng(6).standard_normal(om.osize)
+    e = dict(fwd=rel(m.forward(x), om.forward(x)), adj=rel(m.adjoint(u), om.adjoint(u)),
+             adj_ref=rel(m.adjoint_ref(u), om.adjoint_ref(u)))
+    note("disjoint_windows", lmm=lmm, **e)
+    assert max(e.values()) < TOL
+    m.close()
