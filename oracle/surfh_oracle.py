@@ -329,9 +329,12 @@ def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_deg
                         beta_in_slit - np.mean(beta_in_slit), wavel_axis[ws[0]:ws[1]],
                         scale=(spec.wavel_axis[1] - spec.wavel_axis[0]) / spec.det_pix_size)
     if lam_slice is not None:      # one of n contiguous parts of the window (the parts' outputs add up)
-        i, n = lam_slice
         lin = ws[1] - ws[0]
-        a, b = (lin * i) // n, (lin * (i + 1)) // n
+        if len(lam_slice) == 3:        # ("planes", a, b)
+            _, a, b = lam_slice
+        else:                          # (i, n)
+            i, n = lam_slice
+            a, b = (lin * i) // n, (lin * (i + 1)) // n
         wpsf = wpsf[:, a:b, :]
         ws = (ws[0] + a, ws[0] + b)
 

@@ -4,6 +4,8 @@
 // the epilogue writes the (r, N-r) output pair from their sum / difference.
 #include "dft_fold.h"
 
+#include <cstdlib>
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
@@ -110,6 +112,137 @@ __global__ __launch_bounds__(256) void dft_fold_kernel(DftFoldArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = t.m0 + t.wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * t.h;
+                if (row >= g.rvalid) continue;
+                const float a1 = acc1[mt][nt][r], a2 = acc2[mt][nt][r];
+                if (g.mode == 0) {
+                    d0[(long)row * g.ldc + col] = g.e00 * a1 + g.e01 * a2;
+                    if (row >= 1 && 2 * row != g.Rn) d0[(long)(g.Rn - row) * g.ldc + col] = g.e10 * a1 + g.e11 * a2;
+                } else {
+                    d0[(long)row * g.ldc + col] = g.e00 * a1;
+                    d1[(long)row * g.ldc + col] = g.e11 * a2;
+                }
+            }
+        }
+}
+
+// ---- two products in ONE K loop (the real <-> half-spectrum passes) ------------------------------------------
+// acc1 = A[0]*B1, acc2 = A[1]*B2 with (B1, B2) = (s[k] + s[Kn-k], s[k] - s[Kn-k]) of one source (the mirror row is
+// read once for both), or (src[0][k], src[1][k]) of two sources.  Same epilogues as dft_fold_kernel.
+constexpr int D2_BUF = 2 * BM * ASTR + 2 * BK * BN;     // floats per LDS buffer: A0, A1, B1, B2
+
+__global__ __launch_bounds__(256, 2) void dft_dual_kernel(DftFoldArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, h = lane >> 5;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ar = tid >> 2, ac = (tid & 3) * 4;
+    const int br = tid >> 5, bc = (tid & 31) * 4;
+    const long b = blockIdx.z;
+    const bool eo = g.fold[0] != 0.f;
+    const float *S0 = g.src[0] + b * g.sB;
+    const float *S1 = eo ? S0 : g.src[1] + b * g.sB;
+    const int nk = g.KP / BK;
+    const int kin = g.Kn / 2 + 1;
+
+    f32x16 acc1[2][2], acc2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][j][r] = acc2[i][j][r] = 0.f;
+
+    float4 a00, a01, a10, a11, b10, b11, b20, b21;
+#define D2_ROW(k_, v1_, v2_)                                                                                 \
+    {                                                                                                        \
+        v1_ = *reinterpret_cast<const float4 *>(S0 + (long)(k_) * g.ldb + n0 + bc);                          \
+        if (eo) {                                                                                            \
+            v2_ = make_float4(0.f, 0.f, 0.f, 0.f);                                                           \
+            if (((k_) >= 1) && ((k_) < kin) && (2 * (k_) != g.Kn)) {                                         \
+                const float4 q = *reinterpret_cast<const float4 *>(S0 + (long)(g.Kn - (k_)) * g.ldb + n0 + bc); \
+                v2_ = make_float4(v1_.x - q.x, v1_.y - q.y, v1_.z - q.z, v1_.w - q.w);                       \
+                v1_.x += q.x; v1_.y += q.y; v1_.z += q.z; v1_.w += q.w;                                      \
+            }                                                                                                \
+        } else {                                                                                             \
+            v2_ = *reinterpret_cast<const float4 *>(S1 + (long)(k_) * g.ldb + n0 + bc);                      \
+        }                                                                                                    \
+    }
+#define D2_GLOAD(kt_)                                                                                        \
+    {                                                                                                        \
+        const int k0 = (kt_) * BK;                                                                           \
+        a00 = *reinterpret_cast<const float4 *>(g.A[0] + (long)(m0 + ar) * g.lda + k0 + ac);                 \
+        a01 = *reinterpret_cast<const float4 *>(g.A[0] + (long)(m0 + ar + 64) * g.lda + k0 + ac);            \
+        a10 = *reinterpret_cast<const float4 *>(g.A[1] + (long)(m0 + ar) * g.lda + k0 + ac);                 \
+        a11 = *reinterpret_cast<const float4 *>(g.A[1] + (long)(m0 + ar + 64) * g.lda + k0 + ac);            \
+        D2_ROW(k0 + br, b10, b20);                                                                           \
+        D2_ROW(k0 + br + 8, b11, b21);                                                                       \
+    }
+#define D2_LSTORE(buf_)                                                                                      \
+    {                                                                                                        \
+        float *base = lds + (buf_) * D2_BUF;                                                                 \
+        *reinterpret_cast<float4 *>(base + ar * ASTR + ac) = a00;                                            \
+        *reinterpret_cast<float4 *>(base + (ar + 64) * ASTR + ac) = a01;                                     \
+        *reinterpret_cast<float4 *>(base + BM * ASTR + ar * ASTR + ac) = a10;                                \
+        *reinterpret_cast<float4 *>(base + BM * ASTR + (ar + 64) * ASTR + ac) = a11;                         \
+        float *bb = base + 2 * BM * ASTR;                                                                    \
+        *reinterpret_cast<float4 *>(bb + br * BN + bc) = b10;                                                \
+        *reinterpret_cast<float4 *>(bb + (br + 8) * BN + bc) = b11;                                          \
+        *reinterpret_cast<float4 *>(bb + BK * BN + br * BN + bc) = b20;                                      \
+        *reinterpret_cast<float4 *>(bb + BK * BN + (br + 8) * BN + bc) = b21;                                \
+    }
+    D2_GLOAD(0);
+    D2_LSTORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        D2_GLOAD((kt + 1 < nk) ? kt + 1 : kt);
+        const float *A0 = lds + buf * D2_BUF, *A1 = A0 + BM * ASTR, *B1 = A0 + 2 * BM * ASTR, *B2 = B1 + BK * BN;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            float4 x0[2], x1[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                x0[mt] = *reinterpret_cast<const float4 *>(A0 + (wm * 64 + mt * 32 + l31) * ASTR + 8 * q + 4 * h);
+                x1[mt] = *reinterpret_cast<const float4 *>(A1 + (wm * 64 + mt * 32 + l31) * ASTR + 8 * q + 4 * h);
+            }
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                float v1[2], v2[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int off = (8 * q + 4 * h + m) * BN + wn * 64 + nt * 32 + l31;
+                    v1[nt] = B1[off];
+                    v2[nt] = B2[off];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const float c0 = (m == 0) ? x0[mt].x : (m == 1) ? x0[mt].y : (m == 2) ? x0[mt].z : x0[mt].w;
+                    const float c1 = (m == 0) ? x1[mt].x : (m == 1) ? x1[mt].y : (m == 2) ? x1[mt].z : x1[mt].w;
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc1[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, v1[nt], acc1[mt][nt], 0, 0, 0);
+                        acc2[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, v2[nt], acc2[mt][nt], 0, 0, 0);
+                    }
+                }
+            }
+        }
+        D2_LSTORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef D2_ROW
+#undef D2_GLOAD
+#undef D2_LSTORE
+
+    float *d0 = g.dst[0] + b * g.sC;
+    float *d1 = g.dst[1] ? g.dst[1] + b * g.sC : nullptr;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = n0 + wn * 64 + nt * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                 if (row >= g.rvalid) continue;
                 const float a1 = acc1[mt][nt][r], a2 = acc2[mt][nt][r];
                 if (g.mode == 0) {
@@ -287,6 +420,21 @@ int launch_dft_fold(hipStream_t stream, const DftFoldArgs &g) {
     if (g.MP % BM || g.KP % BK || g.N % BN || g.batch < 1) return (int)hipErrorInvalidValue;
     if (g.mode == 1 && !g.dst[1]) return (int)hipErrorInvalidValue;
     dim3 grid(g.N / BN, g.MP / BM, g.batch);
+    // the single-K-loop kernel covers both real passes: even/odd fold of one source, or two plain sources
+    const bool eo = g.src[0] == g.src[1] && g.fold[0] == 1.f && g.fold[1] == -1.f;
+    const bool two = g.fold[0] == 0.f && g.fold[1] == 0.f;
+    const char *env = getenv("SURFH_FOLD_TWO_PHASE");
+    if ((eo || two) && !(env && env[0] == '1')) {
+        const size_t lds_bytes = (size_t)2 * D2_BUF * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute((const void *)dft_dual_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+            if (e != hipSuccess) return (int)e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(dft_dual_kernel, grid, dim3(256), lds_bytes, stream, g);
+        return (int)hipGetLastError();
+    }
     hipLaunchKernelGGL(dft_fold_kernel, grid, dim3(256), 0, stream, g);
     return (int)hipGetLastError();
 }

@@ -113,6 +113,37 @@ def partition_lambda(costs: Sequence[float], world: int) -> List[List[Tuple[int,
     return out
 
 
+def partition_balanced(costs: Sequence[float], lins: Sequence[int], world: int, snap: int = 16):
+    """Cut the concatenation of all bands' wavelength windows (band order, cost per plane = band cost / planes)
+    into `world` contiguous chunks of equal cost.  A rank gets units (band, ("planes", a, b)); a band cut by a
+    chunk boundary is shared by the ranks on both sides (its partial outputs are all-reduced in its group).
+    Boundaries closer than `snap` planes to a band edge snap to it."""
+    total = float(sum(costs))
+    out: List[List[Tuple[int, tuple]]] = [[] for _ in range(world)]
+    # position -> (band, plane offset)
+    def locate(c):
+        acc = 0.0
+        for k, ck in enumerate(costs):
+            if c <= acc + ck or k == len(costs) - 1:
+                off = int(round((c - acc) / ck * lins[k]))
+                off = min(max(off, 0), lins[k])
+                if off < snap:
+                    off = 0
+                if lins[k] - off < snap:
+                    off = lins[k]
+                return k, off
+            acc += ck
+    cuts = [(0, 0)] + [locate(total * (r + 1) / world) for r in range(world - 1)] + [(len(costs) - 1, lins[-1])]
+    for r in range(world):
+        (k0, a0), (k1, a1) = cuts[r], cuts[r + 1]
+        for k in range(k0, k1 + 1):
+            a = a0 if k == k0 else 0
+            b = a1 if k == k1 else lins[k]
+            if b > a:
+                out[r].append((k, (0, 1) if (a == 0 and b == lins[k]) else ("planes", a, b)))
+    return out
+
+
 def partition_units(costs: Sequence[float], n_pointings: Sequence[int], world: int) -> List[List[Tuple[int, List[int]]]]:
     """Assign (band, pointing subset) units to ranks.  world <= bands: whole bands, longest-processing-time
     greedy; world > bands: every band gets >= 1 ranks (the costliest bands get the extra ones) and its
@@ -164,20 +195,31 @@ class DistributedFusion:
                 for i, s, p in zip(ifus, srfs, pts)]
         self.costs = [band_cost(n_pix, g) for g in geos]
         self.group = None
+        self.unit_groups = []          # (first, last) offsets in this rank's y and the process group, per shared band
         if split == "lambda":
-            self.assignment = partition_lambda(self.costs, world)
+            lins = [g.wslice.stop - g.wslice.start for g in geos]
+            cand = partition_lambda(self.costs, world)
+            load = lambda asg: max(sum(self.costs[k] * (1.0 if u == (0, 1) else
+                                                         ((u[2] - u[1]) / lins[k] if len(u) == 3 else 1.0 / u[1]))
+                                       for k, u in r) for r in asg)
+            bal = partition_balanced(self.costs, lins, world)
+            # whole bands (or equal parts) when that is already balanced, else equal-cost contiguous chunks
+            self.assignment = cand if load(cand) <= 1.05 * load(bal) else bal
             self.units = self.assignment[rank]
             my_ifus = [ifus[k] for k, _ in self.units]
             my_pts = [pts[k] for k, _ in self.units]
-            my_slices = [None if n == 1 else (i, n) for _, (i, n) in self.units]
-            # one process group per shared band; every rank creates every group, in the same order
-            if world > len(ifus):
-                for k in range(len(ifus)):
-                    members = [r for r in range(world) if any(kk == k for kk, _ in self.assignment[r])]
-                    if len(members) > 1:
-                        grp = torch.distributed.new_group(ranks=members)
-                        if rank in members:
-                            self.group = grp
+            my_slices = [None if u == (0, 1) else u for _, u in self.units]
+            # one process group per shared band; every rank creates every group, in the same (band) order
+            groups = {}
+            for k in range(len(ifus)):
+                members = [r for r in range(world) if any(kk == k for kk, _ in self.assignment[r])]
+                if len(members) > 1:
+                    grp = torch.distributed.new_group(ranks=members)
+                    if rank in members:
+                        groups[k] = grp
+            self._band_groups = groups
+            if groups:
+                self.group = next(iter(groups.values()))
         else:
             self.assignment = partition_units(self.costs, [len(p) for p in pts], world)
             self.units = self.assignment[rank]
@@ -201,10 +243,21 @@ class DistributedFusion:
             self.model = model_factory(my_ifus, my_pts, my_slices)
         self.n = self.model.isize
         self._ytmp = None
+        if split == "lambda" and getattr(self, "_band_groups", None):
+            idx = np.cumsum([0] + [int(np.prod(c.oshape)) for c in self.model.channels]) if hasattr(self.model, "channels") \
+                else np.asarray(self.model._idx)
+            for u, (k, _) in enumerate(self.units):
+                if k in self._band_groups:
+                    self.unit_groups.append((int(idx[u]), int(idx[u + 1]), self._band_groups[k]))
 
     def _allreduce(self, t):
         if self.world > 1:
             self.torch.distributed.all_reduce(t)
+
+    def _reduce_shared(self, y):
+        """Sum the partial outputs of every band this rank shares with others (ascending band order on all ranks)."""
+        for a, b, grp in self.unit_groups:
+            self.torch.distributed.all_reduce(y[a:b], group=grp)
 
     def make_data(self, maps, noise_rel=1e-2, seed=1):
         """y_r = A_r maps + N(0, sigma^2), sigma = noise_rel * rms(y_r)."""
@@ -213,12 +266,14 @@ class DistributedFusion:
             x = torch.as_tensor(np.ascontiguousarray(maps, dtype=np.float32), device=self.dev)
             y = torch.empty(self.model.osize, dtype=torch.float32, device=x.device)
             self.model.forward_dev(x, y)
-            if self.group is not None:              # lambda parts of one band: the partial outputs add up
-                torch.distributed.all_reduce(y, group=self.group)
+            self._reduce_shared(y)                  # lambda parts of one band: the partial outputs add up
             if noise_rel:
-                # the ranks sharing a band must draw the same noise: seed by the band, not by the rank
-                g = torch.Generator(device=x.device).manual_seed(seed + (self.units[0][0] if self.group is not None else self.rank))
-                y += torch.randn(y.shape, generator=g, device=x.device, dtype=torch.float32) * (noise_rel * y.square().mean().sqrt())
+                # the ranks sharing a band must draw the same noise: one generator per band, seeded by the band
+                idx = np.asarray(self.model._idx)
+                for u, (k, _) in enumerate(self.units):
+                    g = torch.Generator(device=x.device).manual_seed(seed + 1000 * k)
+                    seg = y[int(idx[u]): int(idx[u + 1])]
+                    seg += torch.randn(seg.shape, generator=g, device=x.device, dtype=torch.float32) * (noise_rel * seg.square().mean().sqrt())
         self._sync()
         return y
 
@@ -230,7 +285,7 @@ class DistributedFusion:
             if self._ytmp is None:
                 self._ytmp = self.torch.empty(self.model.osize, dtype=self.torch.float32, device=d.device)
             self.model.forward_dev(d, self._ytmp)
-            self.torch.distributed.all_reduce(self._ytmp, group=self.group)
+            self._reduce_shared(self._ytmp)
             self.model.adjoint_dev(self._ytmp, q)
             if mu != 1.0:
                 q *= mu

@@ -167,11 +167,17 @@ class ChannelGeometry:
         self.band_wslice = self.wslice
         self.lam_slice = lam_slice
         if lam_slice is not None:
-            i, n = lam_slice
             ws0, lin = self.wslice.start, self.wslice.stop - self.wslice.start
-            if not (0 <= i < n <= lin):
+            if len(lam_slice) == 3:          # ("planes", a, b): explicit plane offsets inside the window
+                _, a, b = lam_slice
+            else:                            # (i, n): the i-th of n equal parts
+                i, n = lam_slice
+                if not (0 <= i < n <= lin):
+                    raise ValueError(f"bad lam_slice {lam_slice} for a window of {lin} planes")
+                a, b = (lin * i) // n, (lin * (i + 1)) // n
+            if not (0 <= a < b <= lin):
                 raise ValueError(f"bad lam_slice {lam_slice} for a window of {lin} planes")
-            self.wslice = slice(ws0 + (lin * i) // n, ws0 + (lin * (i + 1)) // n)
+            self.wslice = slice(ws0 + a, ws0 + b)
         n_out = ceil(self.slicer.npix_slit_alpha_width / srf)
         self.oshape = (len(self.pointings), self.instr.n_slit, len(self.instr.wavel_axis), n_out)
         self.slices_shape = (len(self.pointings), self.instr.n_slit, n_out)

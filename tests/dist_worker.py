@@ -29,6 +29,7 @@ class OracleBackedModel:
         self.om = orc.OracleModel(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"], prob["wavel"],
                                   specs, prob["step_deg"], p, box="direct", lam_slices=lam_slices)
         self.ishape, self.isize, self.osize = self.om.ishape, self.om.isize, self.om.osize
+        self._idx = self.om._idx
 
     @staticmethod
     def _np(t):
@@ -91,7 +92,8 @@ def main():
     same = all(torch.equal(xs[0], t) for t in xs)
     if rank == 0:
         np.savez(os.environ["DIST_OUT"], x=res.x, grad_norm=np.array(res.grad_norm), same=same,
-                 units=np.array([len(u) for u in fus.assignment]), has_group=fus.group is not None)
+                 units=np.array([len(u) for u in fus.assignment]), n_groups=len(fus.unit_groups),
+                 assignment=np.array(repr(fus.assignment)))
     dist.barrier()
     dist.destroy_process_group()
 
