@@ -31,6 +31,7 @@
 
 #include "../../include/surfh_amd.h"
 #include "dft_fold.h"
+#include "dft_rx3.h"
 #include "gemm_f32.h"
 #include "kernels.h"
 
@@ -112,7 +113,9 @@ struct surfh_plan {
     // folded-DFT matrices [MPx][KPx]: cos/sin along alpha; weighted cos/sin for c2r; plain cos/sin for r2c
     float *Cma = nullptr, *Sma = nullptr, *Gc = nullptr, *Gs = nullptr, *Cf = nullptr, *Sf = nullptr;
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
-    bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false;
+    bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
+    unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
+    const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
@@ -549,7 +552,71 @@ int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
 }
 
 // ---- the same two transforms with the symmetry-folded kernel (dft_fold.h): 3x fewer flops --------
+// ---- split-bf16, register-direct variant of the folded passes (dft_rx3.h) ------------------------
+int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
+    const long LP = p->LP;
+    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    DftRx3Args g;   // r2c along beta
+    g.A[0] = p->Cf3; g.A[1] = p->Sf3; g.planeA = (long)p->MPb * p->KPb; g.lda = p->KPb;
+    g.src[0] = src; g.src[1] = src; g.ldb = p->NAP * LP; g.fold[0] = 1.f; g.fold[1] = -1.f; g.Kn = p->Nb;
+    g.dst[0] = p->ycol; g.dst[1] = p->ycol + (long)p->KBP * p->NAP * LP; g.ldc = p->NAP * LP;
+    g.mode = 1; g.e00 = 1.f; g.e11 = -1.f; g.rvalid = hb;
+    g.MP = p->MPb; g.KP = p->KPb; g.N = (int)(p->Na * LP);
+    {
+        Prof pr(p, "dft_rx3_rows_fwd");
+        LAUNCH_OK(launch_dft_rx3(p->stream, g));
+    }
+    {   // c2c along alpha, batched over k_beta; both output components of a tile back to back (second read from cache)
+        DftRx3Args h;
+        h.planeA = (long)p->MPa * p->KPa; h.lda = p->KPa;
+        h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->KBP * p->NAP * LP; h.ldb = LP; h.sB = p->NAP * LP;
+        h.Kn = p->Na; h.ldc = p->KBP * LP; h.sC = LP; h.mode = 0; h.Rn = p->Na; h.rvalid = ha;
+        h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
+        h.A[0] = p->Cma3; h.A[1] = p->Sma3; h.fold[0] = 1.f; h.fold[1] = -1.f; h.dst[0] = dst;
+        h.e00 = 1.f; h.e01 = 1.f; h.e10 = 1.f; h.e11 = -1.f;
+        h.nvar = 2;
+        h.A_alt[0] = p->Sma3; h.A_alt[1] = p->Cma3; h.fold_alt[0] = -1.f; h.fold_alt[1] = 1.f; h.dst_alt = dst + p->PL * LP;
+        h.e_alt[0] = -1.f; h.e_alt[1] = 1.f; h.e_alt[2] = 1.f; h.e_alt[3] = 1.f;
+        Prof pr(p, "dft_rx3_cols_fwd");
+        LAUNCH_OK(launch_dft_rx3(p->stream, h));
+    }
+    return 0;
+}
+
+int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
+    const long LP = p->LP;
+    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    {   // c2c along alpha (optionally with the spectral mix formed in the loader), both components per tile
+        DftRx3Args g;
+        g.planeA = (long)p->MPa * p->KPa; g.lda = p->KPa;
+        g.src[0] = src; g.src[1] = src + p->PL * LP; g.ldb = p->KBP * LP;
+        g.Kn = p->Na; g.ldc = p->KBP * LP; g.mode = 0; g.Rn = p->Na; g.rvalid = ha;
+        g.MP = p->MPa; g.KP = p->KPa; g.N = (int)(hb * LP);
+        g.A[0] = p->Cma3; g.A[1] = p->Sma3; g.fold[0] = 1.f; g.fold[1] = -1.f; g.dst[0] = p->ycol;
+        g.e00 = 1.f; g.e01 = -1.f; g.e10 = 1.f; g.e11 = 1.f;
+        g.nvar = 2;
+        g.A_alt[0] = p->Sma3; g.A_alt[1] = p->Cma3; g.fold_alt[0] = -1.f; g.fold_alt[1] = 1.f;
+        g.dst_alt = p->ycol + (long)p->NAP * p->KBP * LP;
+        g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = -1.f; g.e_alt[3] = 1.f;
+        if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
+        Prof pr(p, mix ? "dft_rx3_cols_inv_mix" : "dft_rx3_cols_inv");
+        LAUNCH_OK(launch_dft_rx3(p->stream, g));
+    }
+    DftRx3Args h;   // c2r along beta, batched over alpha
+    h.A[0] = p->Gc3; h.A[1] = p->Gs3; h.planeA = (long)p->MPb * p->KPb; h.lda = p->KPb;
+    h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->NAP * p->KBP * LP; h.ldb = LP; h.sB = p->KBP * LP;
+    h.dst[0] = dst; h.ldc = p->NAP * LP; h.sC = LP;
+    h.mode = 0; h.e00 = 1.f; h.e01 = -1.f; h.e10 = 1.f; h.e11 = 1.f; h.Rn = p->Nb; h.rvalid = hb;
+    h.MP = p->MPb; h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
+    {
+        Prof pr(p, "dft_rx3_rows_inv");
+        LAUNCH_OK(launch_dft_rx3(p->stream, h));
+    }
+    return 0;
+}
+
 int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
+    if (p->rx3) return rfft2_lam_rx3(p, src, dst);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
     DftFoldArgs g;   // r2c along beta: Zr[kb] = Cf * fold+(cube), Zi[kb] = -Sf * fold-(cube)
@@ -589,6 +656,7 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
 }
 
 int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = false) {
+    if (p->rx3) return irfft2_lam_rx3(p, src, dst, mix);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
     if (!p->fold2) {   // c2c along alpha; with `mix` the source spectrum is formed on the fly as sotf * sum_t tpl * mhat
@@ -649,7 +717,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
         }
         if (rfft2_cube(p, p->cube, p->mhat)) return 1;
     }
-    if (p->T > 0 && p->fuse_mix && !p->dense_dft && !p->fold2) {
+    if (p->T > 0 && p->fuse_mix && !p->dense_dft && !p->fold2 && !(p->rx3 && p->T > 4)) {
         // spectral mix x OTF fused into the loader of the first inverse pass: `spec` is never written
         if (irfft2_cube(p, p->sotf, p->cube, true)) return 1;
     } else {
@@ -786,6 +854,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
                      p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
         hipFree(v);
+    hipFree(p->dft3);
     hipFree(p->dscal);
     hipFree(p->dscratch);
     for (auto &c : p->ch) {
@@ -947,6 +1016,35 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         if (dev_upload(&p->Cma, Cma) || dev_upload(&p->Sma, Sma) || dev_upload(&p->Gc, Gc) || dev_upload(&p->Gs, Gs) ||
             dev_upload(&p->Cf, Cf) || dev_upload(&p->Sf, Sf))
             return bail(1);
+        const char *e5 = getenv("SURFH_DFT_RX3");
+        p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
+        {   // exact three-way bf16 split of the same matrices: x = h + m + l, |x - (h+m+l)| <= 2^-24 |x|
+            std::vector<unsigned short> all;
+            size_t off[6];
+            const std::vector<float> *mats[6] = {&Cma, &Sma, &Gc, &Gs, &Cf, &Sf};
+            for (int i = 0; i < 6; ++i) {
+                const std::vector<float> &M = *mats[i];
+                off[i] = all.size();
+                all.resize(all.size() + 3 * M.size());
+                unsigned short *o = all.data() + off[i];
+                for (size_t j = 0; j < M.size(); ++j) {
+                    float x = M[j], hh, mm;
+                    uint32_t u;
+                    std::memcpy(&u, &x, 4); u &= 0xFFFF0000u; std::memcpy(&hh, &u, 4);
+                    o[j] = (unsigned short)(u >> 16);
+                    float r = x - hh;
+                    std::memcpy(&u, &r, 4); u &= 0xFFFF0000u; std::memcpy(&mm, &u, 4);
+                    o[M.size() + j] = (unsigned short)(u >> 16);
+                    r -= mm;
+                    std::memcpy(&u, &r, 4);
+                    u += 0x7FFFu + ((u >> 16) & 1u);                       // round the last piece to nearest even
+                    o[2 * M.size() + j] = (unsigned short)(u >> 16);
+                }
+            }
+            if (dev_upload(&p->dft3, all)) return bail(1);
+            p->Cma3 = p->dft3 + off[0]; p->Sma3 = p->dft3 + off[1]; p->Gc3 = p->dft3 + off[2];
+            p->Gs3 = p->dft3 + off[3]; p->Cf3 = p->dft3 + off[4]; p->Sf3 = p->dft3 + off[5];
+        }
     }
     // ---- work buffers ---------------------------------------------------------------------
     const size_t nspec = (size_t)2 * p->PL * LP, ncube = (size_t)p->NBP * p->NAP * LP;

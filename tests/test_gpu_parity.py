@@ -299,3 +299,32 @@ def test_disjoint_wavelength_windows(lmm):
     note("disjoint_windows", lmm=lmm, **e)
     assert max(e.values()) < TOL
     m.close()
+
+
+@pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_RX3": "0", "SURFH_FOLD2": "1"},
+                                 {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"}],
+                         ids=["fold_fp32", "fold_fp32_two_launch", "dense_dft", "unfused_mix", "wblur_fp32"])
+def test_alternative_kernel_paths(env):
+    """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green."""
+    cfg = problems.config1()
+    om = problems.oracle_model(cfg, box="direct")
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        m = build_model(cfg)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k)
+            else:
+                os.environ[k] = v
+    try:
+        y = m.forward(cfg["maps"])
+        ey = rel(y, om.forward(cfg["maps"]))
+        rng = np.random.default_rng(5)
+        v = rng.random(y.shape)
+        ea = rel(m.adjoint(v), om.adjoint(v))
+        note("alt_path", env=json.dumps(env), fwd=ey, adj=ea)
+        assert ey < TOL and ea < TOL
+    finally:
+        m.close()

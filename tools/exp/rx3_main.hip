@@ -1,0 +1,53 @@
+// micro-benchmark of the register-direct split-bf16 DFT pass: shapes of config 3's four passes
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+#include "../../surfh_amd/csrc/dft_rx3.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+int main() {
+    const int Na = 251, Nb = 251, ha = 126, hb = 126, NAP = 256, NBP = 256, KBP = 128;
+    const long LP = 4096;
+    const int MP = 128, KP = 128;
+    float *cube, *ycol, *spec;
+    unsigned short *A;
+    CK(hipMalloc(&cube, (size_t)NBP * NAP * LP * 4));
+    CK(hipMalloc(&ycol, (size_t)2 * NAP * KBP * LP * 4));
+    CK(hipMalloc(&spec, (size_t)2 * NAP * KBP * LP * 4));
+    CK(hipMalloc(&A, (size_t)6 * MP * KP * 2));
+    CK(hipMemset(cube, 0, (size_t)NBP * NAP * LP * 4));
+    CK(hipMemset(ycol, 0, (size_t)2 * NAP * KBP * LP * 4));
+    CK(hipMemset(spec, 0, (size_t)2 * NAP * KBP * LP * 4));
+    CK(hipMemset(A, 0, (size_t)6 * MP * KP * 2));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int pass = 0; pass < 4; ++pass) {
+        DftRx3Args g;
+        g.A[0] = A; g.A[1] = A + 3 * MP * KP; g.planeA = (long)MP * KP; g.lda = KP; g.MP = MP; g.KP = KP;
+        const char *name = "";
+        if (pass == 0) {          // r2c along beta
+            name = "rows_fwd"; g.src[0] = cube; g.src[1] = cube; g.ldb = NAP * LP; g.fold[0] = 1; g.fold[1] = -1; g.Kn = Nb;
+            g.dst[0] = ycol; g.dst[1] = ycol + (long)KBP * NAP * LP; g.ldc = NAP * LP; g.mode = 1; g.e11 = -1; g.rvalid = hb; g.N = (int)(Na * LP);
+        } else if (pass == 1) {   // c2c along alpha batched over kb
+            name = "cols_fwd(2v)"; g.src[0] = ycol; g.src[1] = ycol + (long)KBP * NAP * LP; g.ldb = LP; g.sB = NAP * LP; g.fold[0] = 1; g.fold[1] = -1; g.Kn = Na;
+            g.dst[0] = spec; g.ldc = KBP * LP; g.sC = LP; g.mode = 0; g.Rn = Na; g.rvalid = ha; g.e01 = 1; g.e10 = 1; g.e11 = -1; g.N = (int)LP; g.batch = hb;
+            g.nvar = 2; g.A_alt[0] = g.A[1]; g.A_alt[1] = g.A[0]; g.fold_alt[0] = -1; g.fold_alt[1] = 1; g.dst_alt = spec + (long)NAP * KBP * LP;
+        } else if (pass == 2) {   // c2c along alpha, unbatched wide N
+            name = "cols_inv(2v)"; g.src[0] = spec; g.src[1] = spec + (long)NAP * KBP * LP; g.ldb = KBP * LP; g.fold[0] = 1; g.fold[1] = -1; g.Kn = Na;
+            g.dst[0] = ycol; g.ldc = KBP * LP; g.mode = 0; g.Rn = Na; g.rvalid = ha; g.e01 = -1; g.e10 = 1; g.e11 = 1; g.N = (int)(hb * LP);
+            g.nvar = 2; g.A_alt[0] = g.A[1]; g.A_alt[1] = g.A[0]; g.fold_alt[0] = -1; g.fold_alt[1] = 1; g.dst_alt = ycol + (long)NAP * KBP * LP;
+        } else {                  // c2r along beta batched over alpha
+            name = "rows_inv"; g.src[0] = ycol; g.src[1] = ycol + (long)NAP * KBP * LP; g.ldb = LP; g.sB = KBP * LP;
+            g.dst[0] = cube; g.ldc = NAP * LP; g.sC = LP; g.mode = 0; g.e01 = -1; g.e10 = 1; g.e11 = 1; g.Rn = Nb; g.rvalid = hb; g.N = (int)LP; g.batch = Na;
+        }
+        for (int i = 0; i < 3; ++i) { int rc = launch_dft_rx3(st, g); if (rc) { printf("launch rc %d\n", rc); return 1; } }
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) launch_dft_rx3(st, g);
+        CK(hipEventRecord(e1, st));
+        CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("exp %d %-12s %.4f ms\n", RX_EXP, name, ms / reps);
+    }
+    return 0;
+}
