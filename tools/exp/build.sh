@@ -3,11 +3,9 @@
 set -e
 cd "$(dirname "$0")"
 mkdir -p _bin
-for e in 0 1 2 3; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DRX_EXP=$e -o _bin/rx3_exp$e rx3_exp.hip rx3_main.hip &
-done
-wait
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _bin/rx3 ../../surfh_amd/csrc/dft_rx3.hip rx3_main.hip &
 for e in 0 1 2 3 4; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGX_EXP=$e -o _bin/gemm_exp$e gemm_exp.hip gemm_main.hip &
 done
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _bin/gemm_rx3 gemm_rx3.hip gemm_rx3_main.hip &
 wait

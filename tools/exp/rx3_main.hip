@@ -47,7 +47,7 @@ int main() {
         CK(hipEventRecord(e1, st));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-        printf("exp %d %-12s %.4f ms\n", RX_EXP, name, ms / reps);
+        printf("%-12s %.4f ms\n", name, ms / reps);
     }
     return 0;
 }
