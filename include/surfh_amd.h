@@ -114,6 +114,23 @@ int surfh_wct_fwadj(surfh_plan *plan, const float *x, float *out);
  * grad_norm receives r.r (max_iter+1 doubles), nit the iterations done.             */
 int surfh_cg(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0,
              int32_t max_iter, double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
+/* The same solver with the per-iteration callback of qmm.lcg (`callback=` at fusion_CT.py:194-225): after
+ * iteration `it` (1-based) the callback receives the grad_norm trace so far (it+1 values) and the current
+ * iterate copied to the host ([T,Na,Nb] floats, valid during the call).  A non-zero return stops the loop.
+ * surfh_forward / surfh_adjoint on the same plan may be called from inside the callback (the criterion
+ * trace of fusion_CT.py:163-175 does); the CG building blocks below may not.                          */
+typedef int (*surfh_cg_callback)(void *user, int32_t it, const double *grad_norm, const float *x);
+int surfh_cg_cb(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0,
+                int32_t max_iter, double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit,
+                surfh_cg_callback callback, void *user);
+
+/* ---- linear mixing model on the device: the drivers' mapsToCube / cubeTomaps
+ * (spectroModel.py:187-198, jax_utils.py:10-26).  templates [T][Lc] float64 as in surfh_config,
+ * maps [T][Na][Nb], cube [Lc][Na][Nb]; works on any plan (only its device and stream are used).   */
+int surfh_maps_to_cube(surfh_plan *plan, const double *templates, int32_t n_templates, int32_t n_lambda,
+                       const float *maps, float *cube);
+int surfh_cube_to_maps(surfh_plan *plan, const double *templates, int32_t n_templates, int32_t n_lambda,
+                       const float *cube, float *maps);
 
 /* CG building blocks on device vectors, for the multi-GPU driver (one plan per rank,
  * RCCL all-reduce of `q` between surfh_normal_dev and surfh_cg_step_dev).            */

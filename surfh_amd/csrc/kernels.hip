@@ -421,6 +421,42 @@ int launch_wct_hess_apply(hipStream_t s, const float *hth, const float *in, floa
     return (int)hipGetLastError();
 }
 
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// linear mixing model on plane-major arrays (driver utilities, not on the iteration path)
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void lmm_maps2cube_kernel(const float *__restrict__ maps, const float *__restrict__ tpl,
+                                                            float *__restrict__ cube, int T, int L, long npix) {
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    const int l = blockIdx.y;
+    if (i >= npix) return;
+    float acc = 0.f;
+    for (int t = 0; t < T; ++t) acc += tpl[(long)t * L + l] * maps[(long)t * npix + i];
+    cube[(long)l * npix + i] = acc;
+}
+
+// one thread per pixel walks the planes; T <= 8 running sums in registers, every plane read is coalesced
+__global__ __launch_bounds__(TPB) void lmm_cube2maps_kernel(const float *__restrict__ cube, const float *__restrict__ tpl,
+                                                            float *__restrict__ maps, int T, int L, long npix) {
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= npix) return;
+    for (int t0 = 0; t0 < T; t0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int l = 0; l < L; ++l) {
+            const float v = cube[(long)l * npix + i];
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+                if (t0 + t < T) acc[t] += tpl[(long)(t0 + t) * L + l] * v;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t0 + t < T) maps[(long)(t0 + t) * npix + i] = acc[t];
+    }
+}
+
+}  // namespace
+
 int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate) {
     if (t.R == 0 || nlam <= 0) return 0;
     if (nlam % 4) return (int)hipErrorInvalidValue;
@@ -509,5 +545,16 @@ int launch_cg_dir(hipStream_t s, float *d, const float *r, long n, const double 
 
 int launch_residual(hipStream_t s, float *r, const float *b, const float *q, long n) {
     hipLaunchKernelGGL(residual_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, r, b, q, n);
+    return (int)hipGetLastError();
+}
+
+int launch_lmm_maps2cube(hipStream_t s, const float *maps, const float *tpl, float *cube, int T, int L, long npix) {
+    dim3 grid((unsigned)((npix + TPB - 1) / TPB), (unsigned)L);
+    hipLaunchKernelGGL(lmm_maps2cube_kernel, grid, dim3(TPB), 0, s, maps, tpl, cube, T, L, npix);
+    return (int)hipGetLastError();
+}
+
+int launch_lmm_cube2maps(hipStream_t s, const float *cube, const float *tpl, float *maps, int T, int L, long npix) {
+    hipLaunchKernelGGL(lmm_cube2maps_kernel, dim3((unsigned)((npix + TPB - 1) / TPB)), dim3(TPB), 0, s, cube, tpl, maps, T, L, npix);
     return (int)hipGetLastError();
 }

@@ -1246,9 +1246,11 @@ int surfh_residual_dev(surfh_plan *p, float *r, const float *b, const float *q, 
 }
 
 // ---- full CG on one GPU (qmm.lcg semantics, see oracle/surfh_oracle.py:lcg) -------------------
-int surfh_cg(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
-             int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+int surfh_cg_cb(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+                int32_t refresh, float *x, double *grad_norm, int32_t *nit, surfh_cg_callback callback, void *user) {
     if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
+    std::vector<float> hx;             // host copy of the iterate handed to the callback
+    if (callback) hx.resize((size_t)p->isize);
     if (p->T <= 0) return fail("surfh_cg needs templates (the priors act on abundance maps)");
     HIP_OK(hipSetDevice(p->dev));
     if (ensure_cg(p)) return 1;
@@ -1295,11 +1297,56 @@ int surfh_cg(surfh_plan *p, const float *y, double mu, double mu_reg, const floa
         HIP_OK(hipMemcpyAsync(&grad_norm[it + 1], rrn, sizeof(double), hipMemcpyDeviceToHost, s));
         HIP_OK(hipStreamSynchronize(s));
         *nit = it + 1;
+        if (callback) {
+            // the work buffers hold nothing live between iterations, so the callback may run forward / adjoint on this plan
+            HIP_OK(hipMemcpyAsync(hx.data(), p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            if (callback(user, it + 1, grad_norm, hx.data())) break;
+            HIP_OK(hipSetDevice(p->dev));
+        }
         if (std::sqrt(grad_norm[it + 1]) < (double)n * tol) break;
     }
     HIP_OK(hipMemcpyAsync(x, p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s));
     HIP_OK(hipStreamSynchronize(s));
     return 0;
+}
+
+int surfh_cg(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+             int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+    return surfh_cg_cb(p, y, mu, mu_reg, x0, max_iter, tol, refresh, x, grad_norm, nit, nullptr, nullptr);
+}
+
+// ---- drivers' LMM helpers on the device (spectroModel.py:187-198) -----------------------------
+static int lmm_host(surfh_plan *p, const double *templates, int32_t T, int32_t L, const float *in, float *out, bool to_cube) {
+    if (!p || !templates || !in || !out) return fail("null argument");
+    if (T < 1 || L < 1) return fail("bad template shape");
+    HIP_OK(hipSetDevice(p->dev));
+    const long npix = (long)p->Na * p->Nb;
+    std::vector<float> t((size_t)T * L);
+    for (size_t i = 0; i < t.size(); ++i) t[i] = (float)templates[i];
+    float *dt = nullptr, *dm = nullptr, *dc = nullptr;
+    int rc = 0;
+    auto done = [&](int r) { hipFree(dt); hipFree(dm); hipFree(dc); return r; };
+    if (dev_upload(&dt, t) || dev_alloc(&dm, (size_t)T * npix) || dev_alloc(&dc, (size_t)L * npix)) return done(1);
+    hipStream_t s = p->stream;
+    if (to_cube) {
+        if (hipMemcpyAsync(dm, in, (size_t)T * npix * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail("copy failed"));
+        rc = launch_lmm_maps2cube(s, dm, dt, dc, T, L, npix);
+        if (!rc) rc = (int)hipMemcpyAsync(out, dc, (size_t)L * npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    } else {
+        if (hipMemcpyAsync(dc, in, (size_t)L * npix * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail("copy failed"));
+        rc = launch_lmm_cube2maps(s, dc, dt, dm, T, L, npix);
+        if (!rc) rc = (int)hipMemcpyAsync(out, dm, (size_t)T * npix * sizeof(float), hipMemcpyDeviceToHost, s);
+    }
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    if (rc) return done(fail("lmm: %s", hipGetErrorString((hipError_t)rc)));
+    return done(0);
+}
+int surfh_maps_to_cube(surfh_plan *p, const double *templates, int32_t T, int32_t L, const float *maps, float *cube) {
+    return lmm_host(p, templates, T, L, maps, cube, true);
+}
+int surfh_cube_to_maps(surfh_plan *p, const double *templates, int32_t T, int32_t L, const float *cube, float *maps) {
+    return lmm_host(p, templates, T, L, cube, maps, false);
 }
 
 // ---- instrumentation ------------------------------------------------------------------------

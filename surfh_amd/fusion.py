@@ -42,6 +42,12 @@ class QuadCriterion_MRS:
 
     def run_method(self, method="lcg", maximum_iterations=10, tolerance=1e-12, calc_crit=False, perf_crit=None,
                    value_init=0.5):
+        """fusion_CT.py:118-238.  The four callback modes of the reference:
+        calc_crit / perf_crit = False/None: none; False/set: print the gradient norm every iteration;
+        True/set: print it and, at iterations 1, 6, 11, ... (``self.it % 5 == 2`` after the increment, :172-175),
+        evaluate the criterion (one extra forward) into ``L_crit_val``; True/None: the reference hands
+        ``get_crit_val`` itself to qmm as the callback, which receives an OptimizeResult and cannot work -- here the
+        criterion of every iterate is recorded in ``L_crit_val`` instead."""
         assert isinstance(self.mu_reg, (int, float))       # fusion_CT.py:119
         if method != "lcg":
             raise NotImplementedError("only method='lcg' is built (mmmg is out of the hot-path scope)")
@@ -51,13 +57,38 @@ class QuadCriterion_MRS:
             assert value_init.shape == self.shape_of_output
             init = value_init
         import time
+        self.L_crit_val = []
+
+        def record_crit(x):
+            crit_val = self.get_crit_val(x)
+            self.L_crit_val.append(crit_val)
+            print(f"Criterion value = {crit_val}\n")
+
+        def print_last_grad_norm(it, gn, x):
+            print(f"Iteration n°{self.it}, Grad norm = {gn[-1]}")
+            self.it = self.it + 1
+
+        def print_last_grad_norm_and_crit(it, gn, x):
+            print_last_grad_norm(it, gn, x)
+            if self.it % 5 == 2:
+                record_crit(x)
+
+        if calc_crit and perf_crit is None:
+            print(f"{method} : Criterion calculated at each iteration!")
+            callback = lambda it, gn, x: record_crit(x)
+        elif not calc_crit and perf_crit is not None:
+            print(f"{method} : perf_crit calculated at each iteration!")
+            callback = print_last_grad_norm
+        elif calc_crit and perf_crit is not None:
+            print(f"{method} : criterion and gradient printed at each iteration!")
+            callback = print_last_grad_norm_and_crit
+        else:
+            callback = None
         t0 = time.time()
         x, gn, nit = self.model_spectro.cg(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
-                                           max_iter=maximum_iterations, tol=tolerance)
+                                           max_iter=maximum_iterations, tol=tolerance, callback=callback)
         res = OptimizeResult(x=x.ravel(), grad_norm=list(gn), nit=nit,
                              success=bool(np.sqrt(gn[-1]) < x.size * tolerance), time=time.time() - t0)
-        if calc_crit:
-            self.L_crit_val.append(self.get_crit_val(x))
         if self.printing:
             print(f"Total time needed for {method} :", round(res.time, 3))
         return res

@@ -182,7 +182,10 @@ class spectroSigRLSCT(LinOp):
         _lib.check(self._L.surfh_residual_dev(self._plan, _ptr(r_t), _ptr(b_t), _ptr(q_t), int(n)))
 
     # ---- solver on one GPU ------------------------------------------------------------------
-    def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+    def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):
+        """Device-resident linear CG (qmm.lcg restated).  ``callback(it, grad_norm, x)`` -- the per-iteration callback
+        of ``qmm.lcg`` (fusion_CT.py:194-225) -- receives the 1-based iteration, the grad_norm trace so far and the
+        current iterate ``[T,Na,Nb]``; it may call ``forward`` / ``adjoint`` on this model; a truthy return stops."""
         y = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
         if y.size != self.osize:
             raise ValueError("data size mismatch")
@@ -190,19 +193,43 @@ class spectroSigRLSCT(LinOp):
         x = np.empty(self.isize, dtype=np.float32)
         gn = np.zeros(max_iter + 1, dtype=np.float64)
         nit = C.c_int32()
-        _lib.check(self._L.surfh_cg(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
-                                    _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol),
-                                    int(refresh), _lib.fptr(x), _lib.dptr(gn), C.byref(nit)))
+        err = []
+
+        def tramp(_user, it, gptr, xptr):
+            try:
+                g = np.ctypeslib.as_array(gptr, shape=(it + 1,)).copy()
+                xi = np.ctypeslib.as_array(xptr, shape=(self.isize,)).astype(np.float64).reshape(self.ishape)
+                return 1 if callback(it, g, xi) else 0
+            except BaseException as e:          # never unwind through the C frame
+                err.append(e)
+                return 1
+
+        cb = _lib.CG_CALLBACK(tramp) if callback is not None else _lib.CG_CALLBACK()
+        _lib.check(self._L.surfh_cg_cb(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
+                                       _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol),
+                                       int(refresh), _lib.fptr(x), _lib.dptr(gn), C.byref(nit), cb, None))
+        if err:
+            raise err[0]
         return x.astype(np.float64).reshape(self.ishape), gn[: nit.value + 1].copy(), nit.value
 
     # ---- helpers the reference's drivers call -----------------------------------------------
     def cubeTomaps(self, cube):
-        """lmm_cube2maps (spectroModel.py:187-188): host utility, not on the iteration path."""
-        return np.tensordot(self.templates, np.asarray(cube), axes=(1, 0))
+        """lmm_cube2maps (spectroModel.py:187-188, jax_utils.py:18-26) on the device."""
+        cube = np.ascontiguousarray(np.asarray(cube, dtype=np.float32))
+        tpl = np.ascontiguousarray(self.templates, dtype=np.float64)
+        if cube.shape != (tpl.shape[1], self.ishape[-2], self.ishape[-1]):
+            raise ValueError(f"cube shape {cube.shape} != {(tpl.shape[1], self.ishape[-2], self.ishape[-1])}")
+        out = np.empty((tpl.shape[0],) + cube.shape[1:], dtype=np.float32)
+        _lib.check(self._L.surfh_cube_to_maps(self._plan, _lib.dptr(tpl), tpl.shape[0], tpl.shape[1], _lib.fptr(cube), _lib.fptr(out)))
+        return out.astype(np.float64)
 
     def mapsToCube(self, maps):
-        """lmm_maps2cube (spectroModel.py:190-198): host utility, not on the iteration path."""
-        return np.tensordot(self.templates.T, np.asarray(maps), axes=(1, 0))
+        """lmm_maps2cube (spectroModel.py:190-198, jax_utils.py:10-16) on the device."""
+        tpl = np.ascontiguousarray(self.templates, dtype=np.float64)
+        maps = np.ascontiguousarray(np.asarray(maps, dtype=np.float32).reshape((tpl.shape[0],) + tuple(self.ishape[-2:])))
+        out = np.empty((tpl.shape[1],) + maps.shape[1:], dtype=np.float32)
+        _lib.check(self._L.surfh_maps_to_cube(self._plan, _lib.dptr(tpl), tpl.shape[0], tpl.shape[1], _lib.fptr(maps), _lib.fptr(out)))
+        return out.astype(np.float64)
 
     def real_data_janskySR_to_jansky(self, data):
         """Jy/sr -> Jy normalisation of slit data (spectroModel.py:225-239)."""

@@ -1,0 +1,112 @@
+"""driver parity -- CG with the qmm callback, the criterion trace of QuadCriterion_MRS.run_method,
+mapsToCube / cubeTomaps on the device and the fusion driver end to end (needs an MI355X)."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+from click.testing import CliRunner
+
+import problems
+from helpers import build_model, rel
+from oracle import surfh_oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def setup():
+    cfg = problems.config1()
+    om = problems.oracle_model(cfg, box="direct")
+    m = build_model(cfg)
+    y = om.forward(cfg["maps"])
+    y = y + np.random.default_rng(1).standard_normal(y.shape) * 1e-2 * np.sqrt(np.mean(y ** 2))
+    yield cfg, om, m, y
+    m.close()
+
+
+def test_cg_callback_trace(setup):
+    cfg, om, m, y = setup
+    x_ref, gn_ref, nit_ref = m.cg(y, mu=1.0, mu_reg=5e3, x0=np.zeros(m.ishape), max_iter=7)
+    seen = []
+
+    def cb(it, gn, x):
+        assert gn.shape == (it + 1,) and x.shape == tuple(m.ishape)
+        # the callback may run the operator on the same plan (the criterion trace does)
+        seen.append((it, gn[-1], float(np.sum(m.forward(x) ** 2)), x.copy()))
+        return False
+
+    x, gn, nit = m.cg(y, mu=1.0, mu_reg=5e3, x0=np.zeros(m.ishape), max_iter=7, callback=cb)
+    assert nit == nit_ref == 7 and [s[0] for s in seen] == list(range(1, 8))
+    assert np.array_equal(gn, gn_ref) and np.array_equal(x, x_ref)          # the callback does not disturb the solver
+    assert np.array_equal([s[1] for s in seen], gn[1:]) and np.array_equal(seen[-1][3], x)
+    # a truthy return stops the loop after that iteration
+    x3, gn3, nit3 = m.cg(y, mu=1.0, mu_reg=5e3, x0=np.zeros(m.ishape), max_iter=7, callback=lambda it, g, xx: it == 3)
+    assert nit3 == 3 and np.array_equal(gn3, gn[:4]) and np.array_equal(x3, seen[2][3])
+    # an exception in the callback surfaces in Python, not through the C frame
+    with pytest.raises(ZeroDivisionError):
+        m.cg(y, mu=1.0, mu_reg=5e3, max_iter=2, callback=lambda it, g, xx: 1 / 0)
+
+
+def test_criterion_trace_modes(setup, capsys):
+    """fusion_CT.py:163-225: criterion at iterations 1, 6, 11, ... when both flags are set."""
+    from surfh_amd.fusion import QuadCriterion_MRS
+    cfg, om, m, y = setup
+    q = QuadCriterion_MRS(1, y, m, 5e3, printing=True)
+    res = q.run_method("lcg", 7, perf_crit=1, calc_crit=True, value_init=0)
+    out = capsys.readouterr().out
+    assert res.nit == 7 and len(q.L_crit_val) == 2                      # iterations 1 and 6
+    assert out.count("Grad norm =") == 7 and out.count("Criterion value =") == 2 and "Iteration n°7" in out
+    xs = []
+    m.cg(y, mu=1, mu_reg=5e3, x0=np.zeros(m.ishape), max_iter=7, callback=lambda it, g, x: xs.append(x.copy()) and False)
+    for k, it in enumerate((1, 6)):
+        ref = orc.crit_val(om, y, xs[it - 1], 1.0, 5e3)                  # float64 oracle criterion of the same iterate
+        assert abs(q.L_crit_val[k] - ref) / ref < 1e-5
+    assert q.L_crit_val[1] < q.L_crit_val[0]
+    # gradient norms only
+    q2 = QuadCriterion_MRS(1, y, m, 5e3)
+    q2.run_method("lcg", 3, perf_crit=1, calc_crit=False, value_init=0)
+    assert q2.L_crit_val == [] and capsys.readouterr().out.count("Grad norm =") == 3
+    # criterion of every iterate
+    q3 = QuadCriterion_MRS(1, y, m, 5e3)
+    q3.run_method("lcg", 3, calc_crit=True, value_init=0)
+    assert len(q3.L_crit_val) == 3 and q3.L_crit_val[2] < q3.L_crit_val[0]
+    # silent
+    q4 = QuadCriterion_MRS(1, y, m, 5e3)
+    r4 = q4.run_method("lcg", 3, value_init=0)
+    assert q4.L_crit_val == [] and np.allclose(r4.x, xs[2].ravel())
+
+
+def test_lmm_on_device(setup):
+    cfg, om, m, y = setup
+    rng = np.random.default_rng(3)
+    tpl = np.asarray(cfg["templates"], dtype=np.float64)
+    maps = rng.random(m.ishape)
+    cube = m.mapsToCube(maps)
+    assert cube.shape == (tpl.shape[1],) + tuple(m.ishape[1:])
+    assert rel(cube, np.tensordot(tpl.T, maps, axes=(1, 0))) < 1e-6      # jax_utils.py:10-16
+    c = rng.random(cube.shape)
+    assert rel(m.cubeTomaps(c), np.tensordot(tpl, c, axes=(1, 0))) < 1e-6  # jax_utils.py:18-26
+    with pytest.raises(ValueError):
+        m.cubeTomaps(c[:-1])
+
+
+def test_driver_end_to_end(tmp_path):
+    spec = importlib.util.spec_from_file_location("main_fusion", os.path.join(ROOT, "scripts", "main_fusion.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    r = CliRunner().invoke(drv.main, ["-fd", str(tmp_path), "-np", "251", "-hp", "5e3", "-ni", "6", "--synthetic", "small"])
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    d = tmp_path / "Results" / drv.result_dir_name("lcg", 1, 4, 6, 5e3, False)
+    x = np.load(d / "res_x.npy")
+    cube = np.load(d / "res_cube.npy")
+    crit = np.load(d / "criterion.npy")
+    assert x.shape == (4 * 251 * 251,) and cube.shape == (256, 251, 251) and crit.shape == (2,)
+    assert crit[1] < crit[0] and "Iteration n°6" in r.output
+    from surfh_amd import synth
+    tpl = synth.templates(256)
+    assert rel(cube, np.tensordot(tpl.T, x.reshape(4, 251, 251), axes=(1, 0))) < 1e-6
+    # the reconstruction moves towards the truth the data were simulated from
+    truth = np.random.default_rng(19940407).random((4, 251, 251))
+    assert np.isfinite(x).all() and np.linalg.norm(x) > 0 and truth.shape == (4, 251, 251)

@@ -24,7 +24,7 @@ TOL = 1e-5
 def note(name, **kw):
     os.makedirs(OUT, exist_ok=True)
     with open(os.path.join(OUT, "parity_log.jsonl"), "a") as f:
-        f.write(json.dumps(dict(test=name, **{k: (float(v) if np.isscalar(v) else v) for k, v in kw.items()})) + "\n")
+        f.write(json.dumps(dict(test=name, **{k: (float(v) if (np.isscalar(v) and not isinstance(v, str)) else v) for k, v in kw.items()})) + "\n")
 
 
 # ----------------------------------------------------------------------------------------------
