@@ -108,6 +108,11 @@ int surfh_wct_adjoint(surfh_plan *plan, const float *cube, float *maps);     /* 
 /* explicit normal operator through the per-frequency T x T Hessian sum_l tpl tpl' |H_l|^2
  * (mixing.py:102-126,177-212,270-272)                                                          */
 int surfh_wct_fwadj(surfh_plan *plan, const float *x, float *out);
+/* explicit inverse of the regularised normal operator: the minimiser of |y - H x|^2 + sum_t mu_reg[t] |D x_t|^2,
+ * one T x T solve per frequency (QuadCriterion3.run_expsol, surfh/ToolsDir/fusion_mixing.py:309-438;
+ * algorithms.py:156-184).  reg_freq = |D(f)|^2 on the half spectrum [Na][Nb/2+1] (fusion_mixing.py:364-395).
+ * Fails when the matrix is singular at some frequency, where the reference's numpy.linalg.inv raises. */
+int surfh_wct_expsol(surfh_plan *plan, const float *cube, const double *mu_reg, const double *reg_freq, float *maps);
 
 /* ---- regularised least squares by linear CG (fusion_CT.py:118-238 + qmm.lcg) ----
  * minimises  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2).

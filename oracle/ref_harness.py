@@ -117,6 +117,20 @@ def load():
     udft.idft2 = lambda x: np.fft.ifft2(x, norm="ortho")
     udft.rdft2 = lambda x: np.fft.rfft2(x, norm="ortho")
     udft.irdftn = lambda x, shape: np.fft.irfftn(x, s=tuple(shape), axes=tuple(range(-len(shape), 0)), norm="ortho")
+    # only imported by surfh/ToolsDir/fusion_mixing.py (the explicit-inverse solver): the discrete Laplacian impulse
+    # response of udft 3.4.0 restated [memory] -- centre 2*ndim, -1 on the axis neighbours
+    def _laplacian(ndim):
+        ir = np.zeros((3,) * ndim)
+        c = (1,) * ndim
+        ir[c] = 2.0 * ndim
+        for ax in range(ndim):
+            for d in (0, 2):
+                i = list(c)
+                i[ax] = d
+                ir[tuple(i)] = -1.0
+        return ir
+    udft.laplacian = _laplacian
+    udft.diff_ir = lambda ndim, axis: np.reshape(np.array([0.0, -1.0, 1.0]), [3 if a == axis % ndim else 1 for a in range(ndim)])
     sys.modules["udft"] = udft
 
     aljabr = types.ModuleType("aljabr")
@@ -190,6 +204,7 @@ def load():
     ns = types.ModuleType("surfh_ref_ns")
     ns.instru, ns.slicer, ns.python_utils, ns.cython_utils = instru, slicer, python_utils, cython_utils
     ns.cythons_files, ns.nn, ns.channel, ns.model, ns.global_variables = cyf, nn, chan, model, gv
+    ns.fusion_mixing = lambda: importlib.import_module("surfh.ToolsDir.fusion_mixing")   # QuadCriterion3 (explicit inverse)
     ns.mixing = lambda: importlib.import_module("surfh.Models.mixing")   # lazy: pulls algorithms.py + shared-memory helpers
     sys.modules["surfh_ref_ns"] = ns
     return ns

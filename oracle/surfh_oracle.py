@@ -820,3 +820,28 @@ class WCTOracle:
     def fwadj(self, x):                                               # :270-272 via the explicit Hessian (:177-212)
         hth = np.einsum("tl,ul,lij->tuij", self.specs, self.specs, np.abs(self.otf) ** 2)
         return idft(np.einsum("tuij,uij->tij", hth, dft(np.asarray(x, dtype=np.float64))), self.shape)
+
+    def expsol(self, data, mu_reg, gradient="separated"):
+        """QuadCriterion3.run_expsol (surfh/ToolsDir/fusion_mixing.py:309-342,348-438): the minimiser of
+        |y - H x|^2 + sum_t mu_t |D x_t|^2 in closed form, one T x T solve per frequency:
+        (HtH(f) + diag(mu_t |D(f)|^2)) x(f) = (H^T y)(f)."""
+        T = self.specs.shape[0]
+        mu = np.ones(T) * mu_reg if np.isscalar(mu_reg) else np.asarray(mu_reg, dtype=np.float64)
+        hth = np.einsum("tl,ul,lij->ijtu", self.specs, self.specs, np.abs(self.otf) ** 2)
+        hth = hth + reg_freq(self.shape, gradient)[:, :, None, None] * np.diag(mu)[None, None]
+        b = dft(self.adjoint(data))                                   # [T, Na, Nb/2+1]
+        xf = np.linalg.solve(hth, np.moveaxis(b, 0, -1)[..., None])[..., 0]
+        return idft(np.moveaxis(xf, -1, 0), self.shape)
+
+
+def reg_freq(shape, gradient="separated"):
+    """|D(f)|^2 on the half spectrum [Na, Nb/2+1] (fusion_mixing.py:364-395): "separated" = |D_row|^2 + |D_col|^2
+    of the first-difference kernels [-1, 1]; "joint" = |ir2fr(laplacian(2))|^2 (udft's 3x3 Laplacian, restated)."""
+    if gradient == "separated":
+        dr = ir2fr(np.array([-1.0, 1.0])[:, None], shape)
+        dc = ir2fr(np.array([-1.0, 1.0])[None, :], shape)
+        return np.abs(dr) ** 2 + np.abs(dc) ** 2
+    if gradient == "joint":
+        lap = np.array([[0.0, -1.0, 0.0], [-1.0, 4.0, -1.0], [0.0, -1.0, 0.0]])
+        return np.abs(ir2fr(lap, shape)) ** 2
+    raise ValueError(gradient)

@@ -63,6 +63,9 @@ int launch_cg_xupdate(hipStream_t s, float *x, const float *d, long n, const dou
 int launch_cg_dir(hipStream_t s, float *d, const float *r, long n, const double *rr_new, const double *rr_old);
 // r = b - q
 int launch_residual(hipStream_t s, float *r, const float *b, const float *q, long n);
+// (hth + diag(mu reg)) z = in per frequency bin (reg < 0 marks padding bins); *flag |= 1 on a non-positive pivot
+int launch_wct_solve(hipStream_t s, const float *hth, const float *reg, const double *mu, const float *in, float *out, int T,
+                     long PL, int *flag);
 // linear mixing model, plane-major arrays: cube[l][i] = sum_t tpl[t][l] maps[t][i];  maps[t][i] = sum_l tpl[t][l] cube[l][i]
 int launch_lmm_maps2cube(hipStream_t s, const float *maps, const float *tpl, float *cube, int T, int L, long npix);
 int launch_lmm_cube2maps(hipStream_t s, const float *cube, const float *tpl, float *maps, int T, int L, long npix);

@@ -168,6 +168,78 @@ __global__ __launch_bounds__(TPB) void wct_hess_apply_kernel(const float *__rest
     }
 }
 
+// explicit inverse of the regularised normal operator, one thread per frequency bin: solves
+// (HtH(f) + diag(mu_t reg(f))) z = b(f) for the real and the imaginary part of b (HtH is real symmetric for
+// di = dj = 1).  T <= 8 unknowns, Cholesky in fp64 registers; a vanishing pivot raises `flag`.
+__global__ __launch_bounds__(TPB) void wct_solve_kernel(const float *__restrict__ hth, const float *__restrict__ reg,
+                                                        const double *__restrict__ mu, const float *__restrict__ in,
+                                                        float *__restrict__ out, int T, long PL, int *flag) {
+    const long k = (long)blockIdx.x * TPB + threadIdx.x;
+    if (k >= PL) return;
+    const float rg = reg[k];
+    if (rg < 0.f) {                     // padding bin of the spectral layout
+        for (int t = 0; t < T; ++t) out[((long)t * 2 + 0) * PL + k] = out[((long)t * 2 + 1) * PL + k] = 0.f;
+        return;
+    }
+    double A[MAXT][MAXT], br[MAXT], bi[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+#pragma unroll
+        for (int u = 0; u < MAXT; ++u) A[t][u] = (t < T && u < T) ? (double)hth[((long)t * T + u) * PL + k] : (t == u ? 1.0 : 0.0);
+        if (t < T) {
+            A[t][t] += mu[t] * (double)rg;
+            br[t] = in[((long)t * 2 + 0) * PL + k];
+            bi[t] = in[((long)t * 2 + 1) * PL + k];
+        } else {
+            br[t] = bi[t] = 0.0;
+        }
+    }
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < MAXT; ++j) {    // A = L L^T in place (lower triangle), forward substitution on the fly
+        const double ajj = A[j][j];
+        double d = ajj;
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q)
+            if (q < j) d -= A[j][q] * A[j][q];
+        // HtH reaches this kernel in fp32: a pivot below 1e-6 of its diagonal entry is rounding noise, the matrix is singular
+        if (!(d > 1e-6 * ajj)) { bad = true; d = 1.0; }
+        const double l = sqrt(d), il = 1.0 / l;
+        A[j][j] = l;
+#pragma unroll
+        for (int i = 0; i < MAXT; ++i)
+            if (i > j) {
+                double v = A[i][j];
+#pragma unroll
+                for (int q = 0; q < MAXT; ++q)
+                    if (q < j) v -= A[i][q] * A[j][q];
+                A[i][j] = v * il;
+            }
+        double vr = br[j], vi = bi[j];
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q)
+            if (q < j) { vr -= A[j][q] * br[q]; vi -= A[j][q] * bi[q]; }
+        br[j] = vr * il;
+        bi[j] = vi * il;
+    }
+#pragma unroll
+    for (int j = MAXT - 1; j >= 0; --j) {   // back substitution with L^T
+        double vr = br[j], vi = bi[j];
+#pragma unroll
+        for (int q = 0; q < MAXT; ++q)
+            if (q > j) { vr -= A[q][j] * br[q]; vi -= A[q][j] * bi[q]; }
+        br[j] = vr / A[j][j];
+        bi[j] = vi / A[j][j];
+    }
+    if (bad) atomicOr(flag, 1);
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t)
+        if (t < T) {
+            out[((long)t * 2 + 0) * PL + k] = (float)br[t];
+            out[((long)t * 2 + 1) * PL + k] = (float)bi[t];
+        }
+}
+
 // ---------------------------------------------------------------------------------------------
 // sparse row gather vectorised over wavelength: one workgroup = one table row x 1024 wavelengths
 // ---------------------------------------------------------------------------------------------
@@ -556,5 +628,11 @@ int launch_lmm_maps2cube(hipStream_t s, const float *maps, const float *tpl, flo
 
 int launch_lmm_cube2maps(hipStream_t s, const float *cube, const float *tpl, float *maps, int T, int L, long npix) {
     hipLaunchKernelGGL(lmm_cube2maps_kernel, dim3((unsigned)((npix + TPB - 1) / TPB)), dim3(TPB), 0, s, cube, tpl, maps, T, L, npix);
+    return (int)hipGetLastError();
+}
+
+int launch_wct_solve(hipStream_t s, const float *hth, const float *reg, const double *mu, const float *in, float *out, int T,
+                     long PL, int *flag) {
+    hipLaunchKernelGGL(wct_solve_kernel, dim3((unsigned)((PL + TPB - 1) / TPB)), dim3(TPB), 0, s, hth, reg, mu, in, out, T, PL, flag);
     return (int)hipGetLastError();
 }

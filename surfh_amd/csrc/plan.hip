@@ -1195,6 +1195,54 @@ int surfh_wct_fwadj(surfh_plan *p, const float *x, float *out) {
     return 0;
 }
 
+// explicit inverse of the regularised normal operator (QuadCriterion3.run_expsol, fusion_mixing.py:309-438)
+int surfh_wct_expsol(surfh_plan *p, const float *cube, const double *mu_reg, const double *reg_freq, float *maps) {
+    if (wct_check(p)) return 1;
+    if (!maps || !cube || !mu_reg || !reg_freq) return fail("null argument");
+    for (int t = 0; t < p->T; ++t)
+        if (!(mu_reg[t] >= 0.0)) return fail("mu_reg[%d] must be >= 0", t);
+    hipStream_t s = p->stream;
+    if (!p->hth) {
+        if (dev_alloc(&p->hth, (size_t)p->T * p->T * p->PL) || dev_alloc(&p->mhat2, (size_t)p->T * 2 * p->PL)) return 1;
+        LAUNCH_OK(launch_wct_hessian(s, p->sotf, p->tpl, p->hth, p->T, p->PL, p->LP));
+    }
+    // |D(f)|^2 into the padded spectral layout [KAP][KBP]; -1 marks the padding bins
+    const int hb = p->Nb / 2 + 1;
+    std::vector<float> reg((size_t)p->PL, -1.f);
+    for (int a = 0; a < p->Na; ++a)
+        for (int b = 0; b < hb; ++b) {
+            const double v = reg_freq[(size_t)a * hb + b];
+            if (!(v >= 0.0)) return fail("reg_freq must be >= 0");
+            reg[(size_t)a * p->KBP + b] = (float)v;
+        }
+    float *dreg = nullptr;
+    double *dmu = nullptr;
+    int *dflag = nullptr;
+    auto done = [&](int r) { hipFree(dreg); hipFree(dmu); hipFree(dflag); return r; };
+    if (dev_upload(&dreg, reg) || dev_alloc(&dmu, (size_t)p->T) || dev_alloc(&dflag, 1)) return done(1);
+    if (hipMemcpy(dmu, mu_reg, p->T * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(dflag, 0, sizeof(int)) != hipSuccess) return done(fail("copy failed"));
+    // b = H^T y in the Fourier domain (surfh_wct_adjoint up to the inverse transform)
+    if (hipMemcpyAsync(p->io_cube, cube, (size_t)p->Lc * p->Na * p->Nb * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess)
+        return done(fail("copy failed"));
+    int rc = launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP);
+    if (!rc) rc = launch_cube_to_lam_inner(s, p->io_cube, p->cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP);
+    if (rc) return done(fail("launch failed: %s", hipGetErrorString((hipError_t)rc)));
+    if (rfft2_cube(p, p->cube, p->spec)) return done(1);
+    rc = launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP);
+    if (!rc) rc = launch_wct_solve(s, p->hth, dreg, dmu, p->mhat, p->mhat2, p->T, p->PL, dflag);
+    if (rc) return done(fail("launch failed: %s", hipGetErrorString((hipError_t)rc)));
+    if (irfft2_planes(p, p->mhat2, p->maps_pad, p->T)) return done(1);
+    rc = launch_unpad_planes(s, p->maps_pad, p->io_x, p->T, p->Na, p->Nb, p->NAP, p->NBP);
+    int flag = 0;
+    if (!rc) rc = (int)hipMemcpyAsync(maps, p->io_x, p->isize * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (!rc) rc = (int)hipMemcpyAsync(&flag, dflag, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    if (rc) return done(fail("expsol failed: %s", hipGetErrorString((hipError_t)rc)));
+    if (flag) return done(fail("the regularised normal matrix is singular at some frequency (numpy.linalg.inv would raise LinAlgError)"));
+    return done(0);
+}
+
 // ---- CG building blocks ---------------------------------------------------------------------
 int surfh_normal_dev(surfh_plan *p, const float *d, float *q, double mu) {
     if (!p) return fail("null plan");

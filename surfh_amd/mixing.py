@@ -4,6 +4,8 @@
     forward : cube[l] = irfft2( sum_t H[t,l] rfft2(maps[t]) ),  H[t,l] = spec[t,l] pce[l] ir2fr(psf[l])
     adjoint : maps[t] = irfft2( sum_l conj(H[t,l]) rfft2(cube[l]) )
     fwadj   : A^T A through the per-frequency T x T Hessian  sum_l spec[t,l] spec[t',l] |pce[l] otf[l]|^2
+    expsol  : (A^T A + diag(mu_t) D^T D)^-1 A^T y, one T x T solve per frequency -- ``QuadCriterion3`` below
+              (surfh/ToolsDir/fusion_mixing.py:261-438)
 
 ``H`` is never materialised (the reference holds a [T, L, N, N/2+1] complex128 array, mixing.py:40):
 the products are formed on the fly from the OTF and the spectra.
@@ -67,3 +69,56 @@ class Model_WCT(LinOp):
 
     def fwadj(self, x):
         return self._call(self._L.surfh_wct_fwadj, x, self.ishape, self.ishape)
+
+    def expsol(self, data, L_mu, reg_freq):
+        """(H^T H + diag(L_mu) D^T D)^-1 H^T data with |D(f)|^2 = ``reg_freq`` on the half spectrum [Na, Nb/2+1]."""
+        assert tuple(np.shape(data)) == tuple(self.oshape)
+        mu = np.ascontiguousarray(L_mu, dtype=np.float64)
+        reg = np.ascontiguousarray(reg_freq, dtype=np.float64)
+        if mu.shape != (self.n_spec,) or reg.shape != (self.shape_target[0], self.shape_target[1] // 2 + 1):
+            raise ValueError("L_mu must have one entry per map and reg_freq the half-spectrum shape")
+        a = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
+        out = np.empty(int(np.prod(self.ishape)), dtype=np.float32)
+        _lib.check(self._L.surfh_wct_expsol(self._plan, _lib.fptr(a), _lib.dptr(mu), _lib.dptr(reg), _lib.fptr(out)),
+                   np.linalg.LinAlgError)
+        return out.astype(np.float64).reshape(self.ishape)
+
+
+def regularisation_freq(shape_target, gradient="separated"):
+    """|D(f)|^2 of the prior on the half spectrum (Regul_Fusion_Model3, fusion_mixing.py:364-395): "separated" =
+    first differences along rows and columns (kernels [-1, 1]), "joint" = udft's 3x3 Laplacian."""
+    if gradient == "separated":
+        d_row = ir2fr(np.array([-1.0, 1.0])[:, None], shape_target)
+        d_col = ir2fr(np.array([-1.0, 1.0])[None, :], shape_target)
+        return np.abs(d_row) ** 2 + np.abs(d_col) ** 2
+    if gradient == "joint":
+        lap = np.array([[0.0, -1.0, 0.0], [-1.0, 4.0, -1.0], [0.0, -1.0, 0.0]])
+        return np.abs(ir2fr(lap, shape_target)) ** 2
+    raise ValueError(f"gradient must be 'separated' or 'joint', not {gradient!r}")
+
+
+class QuadCriterion3:
+    """Closed-form regularised least squares for ``Model_WCT`` (surfh/ToolsDir/fusion_mixing.py:261-342): same
+    constructor and ``run_expsol()``; ``mu_reg`` is one hyper-parameter or one per abundance map."""
+
+    def __init__(self, data, model, mu_reg, printing=False, gradient="separated"):
+        self.data, self.model = data, model
+        self.n_spec = model.n_spec
+        assert isinstance(mu_reg, (float, int, list, np.ndarray))
+        self.mu_reg = mu_reg
+        if isinstance(mu_reg, (list, np.ndarray)):
+            assert len(mu_reg) == self.n_spec
+            self.L_mu = np.array(mu_reg, dtype=np.float64)
+        else:
+            self.L_mu = np.ones(self.n_spec) * mu_reg          # same mu for all maps
+        self.shape_of_output = (self.n_spec,) + tuple(model.shape_target)
+        self.printing, self.gradient = printing, gradient
+        self._reg = regularisation_freq(model.shape_target, gradient)
+
+    def run_expsol(self):
+        import time
+        t1 = time.time()
+        res = self.model.expsol(self.data, self.L_mu, self._reg)
+        if self.printing:
+            print("Total time needed for expsol = {} sec.".format(round(time.time() - t1, 3)))
+        return res

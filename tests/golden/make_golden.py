@@ -227,7 +227,13 @@ def wct():
     ns = rh.load()
     psfs, specs, shape, pce, x, y = wct_inputs()
     rm = ns.mixing().Model_WCT(psfs, specs, shape, pce)
-    np.savez_compressed(os.path.join(HERE, "model_wct.npz"), forward=rm.forward(x), adjoint=rm.adjoint(y), fwadj=rm.fwadj(x))
+    # explicit-inverse solver (surfh/ToolsDir/fusion_mixing.py:261-438): one hyper-parameter and one per map
+    fm = ns.fusion_mixing()
+    mu_list = [0.3, 1.1, 2.0]
+    np.savez_compressed(os.path.join(HERE, "model_wct.npz"), forward=rm.forward(x), adjoint=rm.adjoint(y), fwadj=rm.fwadj(x),
+                        expsol=fm.QuadCriterion3(y, rm, 0.7, gradient="separated").run_expsol(),
+                        expsol_mu_list=fm.QuadCriterion3(y, rm, mu_list, gradient="separated").run_expsol(),
+                        mu_list=np.array(mu_list))
 
 
 if __name__ == "__main__":

@@ -95,3 +95,33 @@ def test_model_wct_vs_reference():
     assert max(e.values()) < TOL
     assert rel(m.fwadj(x), m.adjoint(m.forward(x))) < 1e-5
     m.close()
+
+
+def test_explicit_inverse_solver_vs_reference():
+    """QuadCriterion3.run_expsol (fusion_mixing.py:261-438) against the reference's own output."""
+    from surfh_amd.mixing import Model_WCT, QuadCriterion3
+    src = open(os.path.join(G, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("def wct_inputs"):src.index("def wct():")], {"problems": problems, "np": np}, ns)
+    psfs, specs, shape, pce, x, y = ns["wct_inputs"]()
+    g = np.load(os.path.join(G, "model_wct.npz"))
+    m = Model_WCT(psfs, specs, shape, pce)
+    r1 = QuadCriterion3(y, m, 0.7, gradient="separated").run_expsol()
+    r2 = QuadCriterion3(y, m, list(g["mu_list"]), gradient="separated").run_expsol()
+    e = dict(scalar=rel(r1, g["expsol"]), per_map=rel(r2, g["expsol_mu_list"]))
+    print(e)
+    assert r1.shape == (3, 40, 36) and max(e.values()) < TOL
+    # "joint" prior (Laplacian kernel restated from udft: parity unpinned against the reference) vs the float64 oracle
+    wo = orc.WCTOracle(psfs, specs, shape, pce)
+    assert rel(QuadCriterion3(y, m, 0.7, gradient="joint").run_expsol(), wo.expsol(y, 0.7, "joint")) < TOL
+    # the closed form is the fixed point of the regularised CG: one application of the normal operator gives H^T y back
+    lhs = m.fwadj(r1) + 0.7 * (orc.diff_r_t(orc.diff_r(r1)) + orc.diff_c_t(orc.diff_c(r1)))
+    assert rel(lhs, m.adjoint(y)) < 1e-4
+    # singular system: mu = 0 and a spectrum basis that is rank deficient -> LinAlgError like numpy.linalg.inv
+    specs2 = specs.copy()
+    specs2[2] = specs2[0] + specs2[1]
+    m2 = Model_WCT(psfs, specs2, shape, pce)
+    with pytest.raises(np.linalg.LinAlgError):
+        QuadCriterion3(y, m2, 0.0).run_expsol()
+    m.close()
+    m2.close()

@@ -209,3 +209,10 @@ def test_model_wct_oracle_vs_reference():
     assert rel(wo.forward(x), g["forward"]) < 1e-13
     assert rel(wo.adjoint(y), g["adjoint"]) < 1e-13
     assert rel(wo.fwadj(x), g["fwadj"]) < 1e-13
+    # explicit-inverse solver: the reference's QuadCriterion3.run_expsol (fusion_mixing.py:309-438)
+    assert rel(wo.expsol(y, 0.7), g["expsol"]) < 1e-12
+    assert rel(wo.expsol(y, g["mu_list"]), g["expsol_mu_list"]) < 1e-12
+    # and it is the minimiser: the normal equations hold
+    xs = wo.expsol(y, 0.7)
+    lhs = wo.fwadj(xs) + 0.7 * (orc.diff_r_t(orc.diff_r(xs)) + orc.diff_c_t(orc.diff_c(xs)))
+    assert rel(lhs, wo.adjoint(y)) < 1e-12
