@@ -152,6 +152,8 @@ def main():
         def symbol(name):
             if name.startswith("gemm_wblur"):
                 return "gemm_nt_bf16x3_kernel" if os.environ.get("SURFH_WBLUR_FP32") != "1" else "gemm_f32_kernel<128, 128>"
+            if name.startswith("dft_rx3_"):
+                return "dft_rx3_kernel"            # four template instances <KIND, MIX> of one kernel (dft_rx3.hip)
             if name.startswith("dft_fold_cols"):
                 return "dft_fold4_kernel"
             if name.startswith("dft_fold_rows"):
@@ -192,7 +194,7 @@ def main():
                 # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
                 # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel
                 # (complex pass) and one of dft_fold_kernel (real pass): half of a transform's bytes per launch.
-                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith("dft_fold") else None
+                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith(("dft_fold", "dft_rx3")) else None
                 ach = bytes_launch / avg_s / 1e9 if bytes_launch else None
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic, "kernel": dom,
@@ -210,6 +212,17 @@ def main():
                        "osize_rank0": int(m.osize), "grad_norm_first_last": [fus.grad_norm[0], fus.grad_norm[-1]]},
             "roofline": roof, "stage_ms_per_step": stage_ms,
         }
+        # the HBM-bound half of the path, whichever kernel group dominates: the four DFT passes of a step against the
+        # algorithmic bytes of its two 2-D transforms (FFT-conv stage)
+        dft = [(k, v) for k, v in groups.items() if k.startswith(("dft_rx3", "dft_fold"))]
+        if dft:
+            n_l = sum(v[0] for _, v in dft)
+            t_s = sum(v[1] for _, v in dft) * 1e-3
+            ach = 0.5 * Lown * (Nf * 8 + N * N * 4) * n_l / t_s / 1e9
+            out["roofline_fft_conv_stage"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                              "frac": ach / HBM_PEAK_GBS, "kernel": "+".join(sorted(k for k, _ in dft)),
+                                              "launches": n_l, "avg_ms": t_s * 1e3 / n_l,
+                                              "traffic": pmc.get("dft_rx3_kernel", {}).get("hbm_bytes_per_launch")}
         if world == 1 and args.cpu_seconds > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)

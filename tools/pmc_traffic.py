@@ -33,7 +33,7 @@ def load(dirname, counter):
 
 
 def short(name):
-    for key in ("gemm_nt_bf16x3_kernel", "dft_fold4_kernel", "dft_fold_kernel", "gemm_f32_kernel<128, 128>", "gemm_f32_kernel<64, 128>", "gemm_f32_kernel<128, 64>",
+    for key in ("gemm_nt_bf16x3_kernel", "dft_rx3_kernel", "dft_fold4_kernel", "dft_fold_kernel", "gemm_f32_kernel<128, 128>", "gemm_f32_kernel<64, 128>", "gemm_f32_kernel<128, 64>",
                 "gemm_f32_kernel<64, 64>", "spmm_rows_kernel", "specmix_fwd_kernel", "specmix_adj_kernel",
                 "fill_zero_kernel", "y_from_cpart_kernel", "ymat_from_y_kernel"):
         if key in name:
@@ -49,13 +49,17 @@ def main():
         s = short(name)
         if s is None:
             continue
-        e = res.setdefault(s, {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0})
-        if name in fetch:
-            e["launches"] = max(e["launches"], fetch[name][0])
-            e["fetch_bytes"] += fetch[name][1] * 1024.0 * 2.0       # gfx950 correction
-        if name in write:
-            e["launches"] = max(e["launches"], write[name][0])
-            e["write_bytes"] += write[name][1] * 1024.0
+        e = res.setdefault(s, {"launches": 0, "fetch_bytes": 0.0, "write_bytes": 0.0, "symbols": {}})
+        # several symbols may share a key (template instances of one kernel): launches add over symbols, and a symbol is
+        # seen once in each of the two passes
+        n = max(fetch[name][0] if name in fetch else 0, write[name][0] if name in write else 0)
+        e["launches"] += n
+        f = fetch[name][1] * 1024.0 * 2.0 if name in fetch else 0.0    # gfx950 correction
+        w = write[name][1] * 1024.0 if name in write else 0.0
+        e["fetch_bytes"] += f
+        e["write_bytes"] += w
+        e["symbols"][name.split("::")[-1]] = {"launches": n, "fetch_bytes_per_launch": f / max(1, n),
+                                              "write_bytes_per_launch": w / max(1, n)}
     for s, e in res.items():
         n = max(1, e["launches"])
         e["hbm_bytes_per_launch"] = (e["fetch_bytes"] + e["write_bytes"]) / n
