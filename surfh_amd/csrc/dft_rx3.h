@@ -34,6 +34,7 @@ struct DftRx3Args {
     // optional second variant on the same data (nvar = 2): each tile is processed twice back to back -- the two
     // output components of a complex pass -- so that the second read of the tile comes from the caches, not HBM
     int nvar = 1;
+    int strided = 0;                           // set by the launcher
     const unsigned short *A_alt[2] = {nullptr, nullptr};
     float fold_alt[2] = {0.f, 0.f};
     float *dst_alt = nullptr;                  // PAIR only

@@ -67,7 +67,9 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
     // The workgroup is persistent: it walks tiles t = blockIdx.x, blockIdx.x + gridDim.x, ... and the software
     // pipeline runs across tile boundaries -- the first loads of the next tile are issued before the last
     // k-step's matrix work and the epilogue stores of the current tile, so that loads, stores and MFMAs overlap.
-    int tile = blockIdx.x * g.nvar;    // unit id = tile index * nvar + variant; a workgroup does all variants of its tiles
+    // unit id = tile index * nvar + variant.  Large launches: a workgroup does all variants of its tiles back to back;
+    // launches with fewer tiles than workgroup slots (`strided`): units are dealt one by one so every slot gets work
+    int tile = g.strided ? (int)blockIdx.x : (int)blockIdx.x * g.nvar;
     // per-tile state (uniform): uniform base + 32-bit lane offset addressing (the launcher checks that the rows fit
     // in 2^31 bytes): one scalar pair and one VGPR per address instead of 64-bit vector arithmetic
     const char *B0, *B1, *A0, *A1;
@@ -236,7 +238,8 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
         unsigned vo = c4 + (unsigned)(em0 + 4 * h) * ldc4;
         unsigned vm = c4 + (unsigned)(g.Rn - em0 - 4 * h) * ldc4;
         asm volatile("" : "+v"(vo), "+v"(vm));
-        const int next = ((tile % g.nvar) + 1 < g.nvar) ? tile + 1 : tile + 1 + ((int)gridDim.x - 1) * g.nvar;
+        const int next = g.strided ? tile + (int)gridDim.x
+                                   : (((tile % g.nvar) + 1 < g.nvar) ? tile + 1 : tile + 1 + ((int)gridDim.x - 1) * g.nvar);
         const bool more = next < ntile;
         if (more) {
             RX_SETUP(next);
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
                 }
         }
         if (!more) break;
-        if (MIX && (next % g.nvar) == 0) RX_MIXTAB();   // every wave finished reading the old table before the last barrier
+        if (MIX && (g.strided || (next % g.nvar) == 0)) RX_MIXTAB();   // every wave finished reading the old table before the last barrier
         __syncthreads();
         RX_BFOLD(0);
         split8(x0, b0h, b0m, b0l);
@@ -310,20 +313,23 @@ int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
     }
     if (g.nvar != 1 && (g.nvar != 2 || g.mode != 0 || !g.dst_alt || !g.A_alt[0] || !g.A_alt[1])) return (int)hipErrorInvalidValue;
     const long ntile = (long)(g.N / 128) * (g.MP / 128) * g.batch;
-    dim3 grid((unsigned)(ntile < slots ? ntile : slots));
+    DftRx3Args a = g;
+    a.strided = (ntile < slots) ? 1 : 0;
+    const long units = a.strided ? ntile * g.nvar : ntile;
+    dim3 grid((unsigned)(units < slots ? units : slots));
     static bool d0 = false, d1 = false, d2 = false, d3 = false;
     if (g.mhat) {
         if (int e = set_lds(dft_rx3_kernel<0, true>, d3, LDS_BYTES + MIX_BYTES)) return e;
-        hipLaunchKernelGGL((dft_rx3_kernel<0, true>), grid, dim3(256), LDS_BYTES + MIX_BYTES, stream, g);
+        hipLaunchKernelGGL((dft_rx3_kernel<0, true>), grid, dim3(256), LDS_BYTES + MIX_BYTES, stream, a);
     } else if (kind == 0) {
         if (int e = set_lds(dft_rx3_kernel<0, false>, d0, LDS_BYTES)) return e;
-        hipLaunchKernelGGL((dft_rx3_kernel<0, false>), grid, dim3(256), LDS_BYTES, stream, g);
+        hipLaunchKernelGGL((dft_rx3_kernel<0, false>), grid, dim3(256), LDS_BYTES, stream, a);
     } else if (kind == 1) {
         if (int e = set_lds(dft_rx3_kernel<1, false>, d1, LDS_BYTES)) return e;
-        hipLaunchKernelGGL((dft_rx3_kernel<1, false>), grid, dim3(256), LDS_BYTES, stream, g);
+        hipLaunchKernelGGL((dft_rx3_kernel<1, false>), grid, dim3(256), LDS_BYTES, stream, a);
     } else {
         if (int e = set_lds(dft_rx3_kernel<2, false>, d2, LDS_BYTES)) return e;
-        hipLaunchKernelGGL((dft_rx3_kernel<2, false>), grid, dim3(256), LDS_BYTES, stream, g);
+        hipLaunchKernelGGL((dft_rx3_kernel<2, false>), grid, dim3(256), LDS_BYTES, stream, a);
     }
     return (int)hipGetLastError();
 }

@@ -49,5 +49,52 @@ int main() {
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%-12s %.4f ms\n", name, ms / reps);
     }
+    // ---- the same two transforms cut into wavelength chunks: the intermediate (half-transformed) array of a chunk is
+    // a small buffer that is rewritten chunk after chunk and should stay in the 256 MB Infinity Cache
+    for (int Lch : {128, 256, 512, 1024}) {
+        float *ys;
+        CK(hipMalloc(&ys, (size_t)2 * KBP * NAP * Lch * 4));
+        CK(hipMemset(ys, 0, (size_t)2 * KBP * NAP * Lch * 4));
+        auto fwd = [&](long l0) {
+            DftRx3Args g;   // r2c along beta, batched over alpha
+            g.A[0] = A; g.A[1] = A + 3 * MP * KP; g.planeA = (long)MP * KP; g.lda = KP; g.MP = MP; g.KP = KP;
+            g.src[0] = cube + l0; g.src[1] = cube + l0; g.ldb = NAP * LP; g.sB = LP; g.batch = Na; g.fold[0] = 1; g.fold[1] = -1; g.Kn = Nb;
+            g.dst[0] = ys; g.dst[1] = ys + (long)KBP * NAP * Lch; g.ldc = (long)NAP * Lch; g.sC = Lch; g.mode = 1; g.e11 = -1; g.rvalid = hb; g.N = Lch;
+            launch_dft_rx3(st, g);
+            DftRx3Args h;   // c2c along alpha, batched over kb
+            h.A[0] = A; h.A[1] = A + 3 * MP * KP; h.planeA = (long)MP * KP; h.lda = KP; h.MP = MP; h.KP = KP;
+            h.src[0] = ys; h.src[1] = ys + (long)KBP * NAP * Lch; h.ldb = Lch; h.sB = (long)NAP * Lch; h.fold[0] = 1; h.fold[1] = -1; h.Kn = Na;
+            h.dst[0] = spec + l0; h.ldc = KBP * LP; h.sC = LP; h.mode = 0; h.Rn = Na; h.rvalid = ha; h.e01 = 1; h.e10 = 1; h.e11 = -1; h.N = Lch; h.batch = hb;
+            h.nvar = 2; h.A_alt[0] = h.A[1]; h.A_alt[1] = h.A[0]; h.fold_alt[0] = -1; h.fold_alt[1] = 1; h.dst_alt = spec + (long)NAP * KBP * LP + l0;
+            launch_dft_rx3(st, h);
+        };
+        auto inv = [&](long l0) {
+            DftRx3Args g;   // c2c along alpha: spectrum chunk -> small intermediate [2][NAP][KBP][Lch]
+            g.A[0] = A; g.A[1] = A + 3 * MP * KP; g.planeA = (long)MP * KP; g.lda = KP; g.MP = MP; g.KP = KP;
+            g.src[0] = spec + l0; g.src[1] = spec + (long)NAP * KBP * LP + l0; g.ldb = KBP * LP; g.sB = LP; g.batch = hb; g.fold[0] = 1; g.fold[1] = -1; g.Kn = Na;
+            g.dst[0] = ys; g.ldc = (long)KBP * Lch; g.sC = Lch; g.mode = 0; g.Rn = Na; g.rvalid = ha; g.e01 = -1; g.e10 = 1; g.e11 = 1; g.N = Lch;
+            g.nvar = 2; g.A_alt[0] = g.A[1]; g.A_alt[1] = g.A[0]; g.fold_alt[0] = -1; g.fold_alt[1] = 1; g.dst_alt = ys + (long)NAP * KBP * Lch;
+            launch_dft_rx3(st, g);
+            DftRx3Args h;   // c2r along beta batched over alpha
+            h.A[0] = A; h.A[1] = A + 3 * MP * KP; h.planeA = (long)MP * KP; h.lda = KP; h.MP = MP; h.KP = KP;
+            h.src[0] = ys; h.src[1] = ys + (long)NAP * KBP * Lch; h.ldb = Lch; h.sB = (long)KBP * Lch;
+            h.dst[0] = cube + l0; h.ldc = NAP * LP; h.sC = LP; h.mode = 0; h.e01 = -1; h.e10 = 1; h.e11 = 1; h.Rn = Nb; h.rvalid = hb; h.N = Lch; h.batch = Na;
+            launch_dft_rx3(st, h);
+        };
+        for (int dir = 0; dir < 2; ++dir) {
+            for (long l0 = 0; l0 < LP; l0 += Lch) { if (dir == 0) fwd(l0); else inv(l0); }
+            CK(hipStreamSynchronize(st));
+            CK(hipEventRecord(e0, st));
+            const int reps = 10;
+            for (int i = 0; i < reps; ++i)
+                for (long l0 = 0; l0 < LP; l0 += Lch) { if (dir == 0) fwd(l0); else inv(l0); }
+            CK(hipEventRecord(e1, st));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("chunked %s  Lch=%4d  %.4f ms per 2-D transform (intermediate %.0f MB)\n", dir == 0 ? "rfft2 " : "irfft2", Lch, ms / reps,
+                   2.0 * KBP * NAP * Lch * 4 / 1e6);
+        }
+        CK(hipFree(ys));
+    }
     return 0;
 }
