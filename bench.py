@@ -151,7 +151,9 @@ def main():
         # HIP-event names -> kernel symbols as rocprofv3 reports them (profiles/*_kernel_stats_*.csv)
         def symbol(name):
             if name.startswith("gemm_wblur"):
-                return "gemm_nt_bf16x3_kernel" if os.environ.get("SURFH_WBLUR_FP32") != "1" else "gemm_f32_kernel<128, 128>"
+                if os.environ.get("SURFH_WBLUR_FP32") == "1":
+                    return "gemm_f32_kernel<128, 128>"
+                return "gemm_nt_bf16x3_pc_kernel" if os.environ.get("SURFH_WBLUR_PC") != "0" else "gemm_nt_bf16x3_kernel"
             if name.startswith("dft_rx3_"):
                 return "dft_rx3_kernel"            # four template instances <KIND, MIX> of one kernel (dft_rx3.hip)
             if name.startswith("dft_fold_cols"):

@@ -32,3 +32,6 @@ int launch_gemm_f32(hipStream_t stream, const GemmArgs &g);
 // see gemm_bf16x3.hip).  B0/ldb describe B as [N][K]; M, N multiples of 128.
 int launch_gemm_nt_bf16x3(hipStream_t stream, const GemmArgs &g);
 
+// The same product with a producer / consumer workgroup (8 waves, 128 x 256 tile, one workgroup per CU: gemm_pc3.hip).
+// N may be any multiple of 128.
+int launch_gemm_nt_bf16x3_pc(hipStream_t stream, const GemmArgs &g);

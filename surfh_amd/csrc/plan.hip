@@ -113,6 +113,8 @@ struct surfh_plan {
     // folded-DFT matrices [MPx][KPx]: cos/sin along alpha; weighted cos/sin for c2r; plain cos/sin for r2c
     float *Cma = nullptr, *Sma = nullptr, *Gc = nullptr, *Gs = nullptr, *Cf = nullptr, *Sf = nullptr;
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
+    int n_cu = 256;
+    bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
@@ -391,8 +393,28 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     return 0;
 }
 
-int pick_split(const Channel &c, int forced) {
+int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu) {
     if (forced > 0) return (c.K % (32 * forced) == 0) ? forced : 1;
+    if (pc_kernel) {
+        // producer/consumer kernel (128 x 256 tiles, one workgroup per CU).  The slab length is set by accuracy first:
+        // accumulation chains of the split-bf16 products stay unbiased up to about 1024 k (gemm_pc3.hip header), so
+        // take the fewest slabs with K / s <= 1088; among slab counts up to 1.5x that, the one that fills the last
+        // round of workgroups best.
+        const long tiles = (long)(c.NP / 128) * ((c.LdetP + 255) / 256);
+        const int steps = c.K / 32;
+        int smin = 0;
+        for (int s = 1; s <= steps; ++s)
+            if (steps % s == 0 && steps / s <= 34) { smin = s; break; }
+        if (!smin) return 1;
+        int best = smin;
+        double best_t = -1.0;
+        for (int s = smin; s <= smin + smin / 2 && s <= steps; ++s) {
+            if (steps % s) continue;
+            const double t = (double)((tiles * s + n_cu - 1) / n_cu) * (steps / s) + 3.0 * s;
+            if (best_t < 0 || t < best_t) { best_t = t; best = s; }
+        }
+        return best;
+    }
     const int bm = (c.NP % 128 == 0) ? 128 : 64, bn = (c.LdetP % 128 == 0) ? 128 : 64;
     const long tiles = (long)(c.NP / bm) * (c.LdetP / bn);
     int best = 1;
@@ -748,7 +770,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
                 LAUNCH_OK(launch_gemm_f32(s, g));
             } else {
                 g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
-                LAUNCH_OK(launch_gemm_nt_bf16x3(s, g));
+                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(s, g) : launch_gemm_nt_bf16x3(s, g));
             }
         }
         {
@@ -792,7 +814,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
                 LAUNCH_OK(launch_gemm_f32(s, g));
             } else {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
-                LAUNCH_OK(launch_gemm_nt_bf16x3(s, g));
+                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(s, g) : launch_gemm_nt_bf16x3(s, g));
             }
         }
         {
@@ -888,6 +910,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
 
     surfh_plan *p = new surfh_plan();
     p->dev = cfg->device;
+    if (hipDeviceGetAttribute(&p->n_cu, hipDeviceAttributeMultiprocessorCount, cfg->device) != hipSuccess || p->n_cu < 1) p->n_cu = 256;
     auto bail = [&](int) {
         surfh_plan_destroy(p);
         return 1;
@@ -991,6 +1014,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->fuse_mix = !(e3 && e3[0] == '1');
         const char *e4 = getenv("SURFH_WBLUR_FP32");
         p->wblur_fp32 = e4 && e4[0] == '1';       // R / R^T on the fp32-input MFMA instead of the split-bf16 path
+        const char *e6 = getenv("SURFH_WBLUR_PC");
+        p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
         const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
         p->MPa = (ha + 127) / 128 * 128; p->KPa = (ha + 15) / 16 * 16;
         p->MPb = (hb + 127) / 128 * 128; p->KPb = (hb + 15) / 16 * 16;
@@ -1070,7 +1095,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         c.yoff = yoff;
         yoff += c.ysize;
         if (c.bsum) continue;
-        c.splitK = pick_split(c, cfg->split_k_forward);
+        c.splitK = pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu);
         if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
         hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));
     }
@@ -1497,7 +1522,7 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
             for (int n = 0; n < N; ++n) bt[(size_t)n * K + k] = B[(size_t)k * N + n];
         HIP_OK(hipMemcpy(dB, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
         g.ldb = K;
-        rc = launch_gemm_nt_bf16x3(nullptr, g);
+        rc = (mode[1] == 'p') ? launch_gemm_nt_bf16x3_pc(nullptr, g) : launch_gemm_nt_bf16x3(nullptr, g);   // "1p": producer/consumer kernel
     } else {
         rc = launch_gemm_f32(nullptr, g);
     }

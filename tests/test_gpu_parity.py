@@ -67,6 +67,26 @@ def test_gemm_split_bf16_selftest():
         os.environ.pop("SURFH_SELFTEST_BF16X3")
 
 
+def test_gemm_producer_consumer_selftest():
+    """The 8-wave producer/consumer form of the split-bf16 GEMM (gemm_pc3.hip): same accuracy, ragged last 256-column
+    tile, split K."""
+    from surfh_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(2)
+    os.environ["SURFH_SELFTEST_BF16X3"] = "1p"
+    try:
+        for (M, N, K, sk) in [(128, 128, 32, 1), (128, 256, 64, 1), (256, 384, 512, 2), (384, 640, 1056, 3)]:
+            A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, K)))).astype(np.float32)
+            B = rng.standard_normal((K, N)).astype(np.float32) + np.arange(N, dtype=np.float32)[None, :] * 0.02
+            Cg = np.empty((M, N), dtype=np.float32)
+            _lib.check(L.surfh_gemm_selftest(0, M, N, K, sk, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
+            e = rel(Cg, A.astype(np.float64) @ B.astype(np.float64))
+            note("gemm_bf16x3_pc", M=M, N=N, K=K, sk=sk, err=e)
+            assert e < 5e-7, (M, N, K, sk, e)
+    finally:
+        os.environ.pop("SURFH_SELFTEST_BF16X3")
+
+
 @pytest.fixture(scope="module")
 def c1():
     cfg = problems.config1()
@@ -302,8 +322,9 @@ def test_disjoint_wavelength_windows(lmm):
 
 
 @pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_RX3": "0", "SURFH_FOLD2": "1"},
-                                 {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"}],
-                         ids=["fold_fp32", "fold_fp32_two_launch", "dense_dft", "unfused_mix", "wblur_fp32"])
+                                 {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
+                                 {"SURFH_WBLUR_PC": "0"}],
+                         ids=["fold_fp32", "fold_fp32_two_launch", "dense_dft", "unfused_mix", "wblur_fp32", "wblur_4wave"])
 def test_alternative_kernel_paths(env):
     """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green."""
     cfg = problems.config1()

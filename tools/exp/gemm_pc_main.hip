@@ -1,0 +1,73 @@
+// micro-benchmark + spot check: producer/consumer split-bf16 GEMM (gemm_pc3.hip) against the shipped 4-wave kernel
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <random>
+#include <vector>
+#include "../../surfh_amd/csrc/gemm_f32.h"
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int run(int M, int N, int K, int sk, const char *name, bool check) {
+    std::mt19937 rng(7);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    std::vector<float> A((size_t)M * K), B((size_t)N * K);
+    for (auto &v : A) v = nd(rng) + 0.5f;
+    for (auto &v : B) v = nd(rng) * 0.05f;
+    float *dA, *dB, *dC;
+    const int nslab = sk;
+    CK(hipMalloc(&dA, A.size() * 4)); CK(hipMalloc(&dB, B.size() * 4)); CK(hipMalloc(&dC, (size_t)nslab * M * N * 4));
+    CK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+    GemmArgs g;
+    g.A0 = dA; g.lda = K; g.B0 = dB; g.ldb = K; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.splitK = sk; g.sCsplit = (long)M * N;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int which = 0; which < 2; ++which) {
+        if (which == 0 && N % 128) continue;
+        auto launch = [&]() { return which ? launch_gemm_nt_bf16x3_pc(st, g) : launch_gemm_nt_bf16x3(st, g); };
+        CK(hipMemset(dC, 0xFF, (size_t)nslab * M * N * 4));
+        int rc = launch();
+        if (rc) { printf("launch rc %d\n", rc); return 1; }
+        CK(hipStreamSynchronize(st));
+        double num = 0, den = 0;
+        if (check) {
+            std::vector<float> C((size_t)nslab * M * N);
+            CK(hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost));
+            for (int t = 0; t < 3000; ++t) {
+                const int m = (int)(((long)t * 7919 + 13) % M), n = (t < 64) ? N - 1 - t % std::min(N, 64) : (int)(((long)t * 104729 + 7) % N);
+                double ref = 0, got = 0;
+                for (int k = 0; k < K; ++k) ref += (double)A[(size_t)m * K + k] * (double)B[(size_t)n * K + k];
+                for (int s = 0; s < (which ? nslab : sk); ++s) got += C[(size_t)s * M * N + (size_t)m * N + n];
+                num += (got - ref) * (got - ref); den += ref * ref;
+            }
+        }
+        for (int i = 0; i < 3; ++i) launch();
+        CK(hipEventRecord(e0, st));
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) launch();
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        printf("%-8s %-9s M=%d N=%d K=%d sk=%d  rel L2 err %.3g   %.4f ms  %.1f TF/s fp32-equivalent\n", name, which ? "prod/cons" : "shipped", M, N, K, sk,
+               check ? std::sqrt(num / den) : -1.0, ms, 2.0 * M * N * K / ms * 1e-9);
+    }
+    hipFree(dA); hipFree(dB); hipFree(dC);
+    return 0;
+}
+
+int main() {
+#ifdef PC_EXP
+    printf("experiment %d\n", PC_EXP);
+    if (run(1664, 1408, 16896, 3, "forward", false)) return 1;
+    return 0;
+#endif
+    if (run(128, 256, 64, 1, "tiny", true)) return 1;
+    if (run(128, 128, 96, 1, "half", true)) return 1;
+    if (run(256, 384, 512, 2, "ragged", true)) return 1;
+    // config 3, band 2C: forward  yT[NP][LdetP] = Xs[NP][K] W[LdetP][K]^T ; adjoint  XsT[NP][K] = ymat[NP][LdetP] Wt[K][LdetP]^T
+    if (run(1664, 1408, 16896, 6, "forward", true)) return 1;
+    if (run(1664, 1408, 16896, 3, "forward", false)) return 1;
+    if (run(1664, 1408, 16896, 8, "forward", false)) return 1;
+    if (run(1664, 1408, 16896, 16, "forward", false)) return 1;
+    if (run(1664, 16896, 1408, 1, "adjoint", true)) return 1;
+    return 0;
+}
