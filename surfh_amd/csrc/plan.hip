@@ -292,7 +292,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                     const int s = sb.first, b = sb.second;
                     const double ws = d.slit_weights[(long)s * c->nbs + b];
                     std::vector<std::pair<int64_t, float>> row;
-                    row.reserve(4 * c->srf);
+                    std::map<int64_t, double> acc;
                     for (int r = 0; r < c->srf; ++r) {
                         const int i = (c->alpha0 + a * c->srf + r) % c->na;
                         const long li = (long)pt * nloc + (long)i * c->nb + j;
@@ -301,8 +301,11 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                         const double w[4] = {(1. - y0) * (1. - y1), (1. - y0) * y1, y0 * (1. - y1), y0 * y1};
                         const int da[4] = {0, 0, 1, 1}, db[4] = {0, 1, 0, 1};
                         for (int k = 0; k < 4; ++k)
-                            if (w[k] * ws != 0.0) row.push_back({pix_off(i0 + da[k], i1 + db[k]), (float)(w[k] * ws)});
+                            if (w[k] * ws != 0.0) acc[pix_off(i0 + da[k], i1 + db[k])] += w[k] * ws;
                     }
+                    // consecutive samples of the box window share two of their four cube pixels: one tap per distinct
+                    // pixel (about 16 instead of 28 reads per output element)
+                    for (auto &e : acc) row.push_back({e.first, (float)e.second});
                     f.rows.push_back(std::move(row));
                     f.dst.push_back(xs_off(pt, s, a, b));
                 }
