@@ -96,6 +96,12 @@ struct surfh_plan {
     int dev = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // second stream: the spectral-blur GEMMs run here while the gather / scatter of the neighbouring channel runs on
+    // `stream` (different units: matrix cores vs L2 bandwidth, and the GEMM leaves registers for them on every SIMD)
+    hipStream_t stream2 = nullptr;
+    bool overlap = false;
+    std::vector<hipEvent_t> sync_ev;             // dependency events between the two streams (no timing)
+    size_t sync_next = 0;
     int Na = 0, Nb = 0, Lc = 0, T = 0, NAP = 0, NBP = 0, KAP = 0, KBP = 0;
     long PL = 0, PLc = 0;
     int lo = 0, hi = 0, Lown = 0, LP = 0;
@@ -138,7 +144,8 @@ struct Prof {
     surfh_plan *p;
     ProfRec r;
     bool on;
-    Prof(surfh_plan *pl, const char *name) : p(pl), on(pl->prof) {
+    hipStream_t st;
+    Prof(surfh_plan *pl, const char *name, hipStream_t stream = nullptr) : p(pl), on(pl->prof), st(stream ? stream : pl->stream) {
         if (!on) return;
         r.name = name;
         for (hipEvent_t *e : {&r.a, &r.b}) {
@@ -149,18 +156,34 @@ struct Prof {
                 hipEventCreate(e);
             }
         }
-        hipEventRecord(r.a, p->stream);
+        hipEventRecord(r.a, st);
     }
     ~Prof() {
         if (!on) return;
-        hipEventRecord(r.b, p->stream);
+        hipEventRecord(r.b, st);
         p->pending.push_back(r);
     }
 };
 
+// make stream `to` wait for the work enqueued so far on stream `from`
+int chain(surfh_plan *p, hipStream_t from, hipStream_t to) {
+    if (from == to) return 0;
+    if (p->sync_next == p->sync_ev.size()) {
+        hipEvent_t e;
+        HIP_OK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        p->sync_ev.push_back(e);
+    }
+    hipEvent_t e = p->sync_ev[p->sync_next++];
+    if (p->sync_next >= 64) p->sync_next = 0;       // ring: an event is re-recorded long after its waiters were enqueued
+    HIP_OK(hipEventRecord(e, from));
+    HIP_OK(hipStreamWaitEvent(to, e, 0));
+    return 0;
+}
+
 void prof_collect(surfh_plan *p) {
     if (p->pending.empty()) return;
     hipStreamSynchronize(p->stream);
+    if (p->stream2) hipStreamSynchronize(p->stream2);
     for (auto &r : p->pending) {
         float ms = 0.f;
         hipEventElapsedTime(&ms, r.a, r.b);
@@ -752,6 +775,8 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
         }
         if (irfft2_cube(p, p->spec, p->cube)) return 1;
     }
+    // gather on the main stream, spectral-blur GEMM + slab sum on the second one: GEMM(c) overlaps gather(c+1)
+    hipStream_t sB = (p->overlap && p->stream2) ? p->stream2 : s;
     for (auto &c : p->ch) {
         {
             Prof pr(p, "spmm_gather_fwd");
@@ -762,31 +787,37 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             LAUNCH_OK(launch_cube_from_lam_inner(s, c.Xs + c.shift, y + c.yoff, 0, c.Lin, 1, c.P * c.S * c.aout, 1, c.LinP));
             continue;
         }
+        if (chain(p, s, sB)) return 1;
         GemmArgs g;   // y^T[n][l'] = sum_k Xs[n][k] W[l'][k]
         g.A0 = c.Xs; g.lda = c.K;
         g.C = c.Cpart; g.ldc = c.LdetP;
         g.M = c.NP; g.N = c.LdetP; g.K = c.K; g.splitK = c.splitK; g.sCsplit = (long)c.NP * c.LdetP;
         {
-            Prof pr(p, "gemm_wblur_fwd");
+            Prof pr(p, "gemm_wblur_fwd", sB);
             if (p->wblur_fp32) {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [K][N]
-                LAUNCH_OK(launch_gemm_f32(s, g));
+                LAUNCH_OK(launch_gemm_f32(sB, g));
             } else {
                 g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
-                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(s, g) : launch_gemm_nt_bf16x3(s, g));
+                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
         {
-            Prof pr(p, "y_from_cpart");
-            LAUNCH_OK(launch_y_from_cpart(s, c.Cpart, (long)c.NP * c.LdetP, c.splitK, y + c.yoff, c.P * c.S, c.Ldet,
+            Prof pr(p, "y_from_cpart", sB);
+            LAUNCH_OK(launch_y_from_cpart(sB, c.Cpart, (long)c.NP * c.LdetP, c.splitK, y + c.yoff, c.P * c.S, c.Ldet,
                                           c.aout, c.LdetP));
         }
     }
+    if (chain(p, sB, s)) return 1;     // everything after this call sees y complete
     return 0;
 }
 
 int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
     hipStream_t s = p->stream;
+    // detector-side work (y -> ymat, R^T GEMM) on the second stream, cube-side scatter on the main one: GEMM(c+1)
+    // overlaps scatter(c); the scatters stay in channel order on one stream because their windows overlap
+    hipStream_t sB = (p->overlap && p->stream2) ? p->stream2 : s;
+    if (chain(p, s, sB)) return 1;     // y (and the previous users of Xs / ymat) are ordered before the second stream's work
     {
         Prof pr(p, "fill_zero");
         LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
@@ -803,23 +834,24 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             continue;
         }
         {
-            Prof pr(p, "ymat_from_y");
-            LAUNCH_OK(launch_ymat_from_y(s, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP));
+            Prof pr(p, "ymat_from_y", sB);
+            LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP));
         }
         GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
         g.A0 = c.ymat; g.lda = c.LdetP;
         g.C = c.Xs; g.ldc = c.K;
         g.M = c.NP; g.N = c.K; g.K = c.LdetP;
         {
-            Prof pr(p, "gemm_wblur_adj");
+            Prof pr(p, "gemm_wblur_adj", sB);
             if (p->wblur_fp32) {
                 g.B0 = c.W; g.ldb = c.K;             // B as [K'=l'][N'=k]
-                LAUNCH_OK(launch_gemm_f32(s, g));
+                LAUNCH_OK(launch_gemm_f32(sB, g));
             } else {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
-                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(s, g) : launch_gemm_nt_bf16x3(s, g));
+                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
+        if (chain(p, sB, s)) return 1;
         {
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
             LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
@@ -893,6 +925,8 @@ int surfh_plan_destroy(surfh_plan *p) {
         hipEventDestroy(r.b);
     }
     for (auto e : p->pool) hipEventDestroy(e);
+    for (hipEvent_t e : p->sync_ev) hipEventDestroy(e);
+    if (p->stream2) hipStreamDestroy(p->stream2);
     if (p->own_stream && p->stream) hipStreamDestroy(p->stream);
     delete p;
     return 0;
@@ -1017,6 +1051,11 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->fuse_mix = !(e3 && e3[0] == '1');
         const char *e4 = getenv("SURFH_WBLUR_FP32");
         p->wblur_fp32 = e4 && e4[0] == '1';       // R / R^T on the fp32-input MFMA instead of the split-bf16 path
+        // measured on config 3: 7.64 -> 7.53 ms per iteration (+1.5 %), the overlapped kernels slow each other down by
+        // almost what they save; off by default so that per-kernel times in profiles stay those of a kernel running alone
+        const char *e7 = getenv("SURFH_OVERLAP");
+        p->overlap = e7 && e7[0] == '1';
+        if (p->overlap && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
         const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
