@@ -44,3 +44,4 @@ struct DftRx3Args {
     long PL = 0, KBP = 0;
 };
 int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g);
+bool dft_rx3_supported(int Na, int Nb, long NAP, long KBP, long LP);

@@ -15,8 +15,7 @@ constexpr int PIECE = 128 * RS;               // one bf16 piece of one 128-row m
 constexpr int IMG = 3 * PIECE;
 constexpr int BUF = 2 * IMG;                  // both matrices
 constexpr size_t LDS_BYTES = (size_t)2 * BUF * sizeof(unsigned short);
-constexpr int MIX_ROWS = 256;                 // rows of the per-workgroup spectral-mix table ([k][re/im] float4)
-constexpr size_t MIX_BYTES = (size_t)MIX_ROWS * 2 * sizeof(float4);
+constexpr int MIX_ROWS_MAX = 2048;            // rows of the per-workgroup spectral-mix table ([k][re/im] float4): 64 KB at most
 
 __device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
 
@@ -300,11 +299,14 @@ int set_lds(K kernel, bool &done, size_t bytes) {
 int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
     if (g.MP % 128 || g.KP % BK || g.N % 128 || g.batch < 1) return (int)hipErrorInvalidValue;
     if (g.mode == 1 && !g.dst[1]) return (int)hipErrorInvalidValue;
-    if ((double)(g.Kn > g.KP ? g.Kn + 1 : g.KP) * (double)g.ldb * 4.0 + 4.0 * g.N >= 2147483648.0) return (int)hipErrorInvalidValue;
-    if ((double)((g.mode == 0 ? g.Rn : g.rvalid) + 1) * (double)g.ldc * 4.0 + 4.0 * g.N >= 2147483648.0) return (int)hipErrorInvalidValue;
+    // lane offsets are unsigned 32-bit relative to the tile's base: all rows of a tile column must lie within 4 GB
+    if ((double)(g.Kn > g.KP ? g.Kn + 1 : g.KP) * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
+    if ((double)((g.mode == 0 ? g.Rn : g.rvalid) + 1) * (double)g.ldc * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
     const bool folded = g.fold[0] != 0.f || g.fold[1] != 0.f || (g.nvar == 2 && (g.fold_alt[0] != 0.f || g.fold_alt[1] != 0.f));
     const int kind = !folded ? 2 : (g.src[0] == g.src[1] ? 1 : 0);
-    if (g.mhat && (kind != 0 || g.LP % 128 || g.T < 1 || g.T > 4 || g.Kn > MIX_ROWS || g.KP > MIX_ROWS)) return (int)hipErrorInvalidValue;
+    const int mix_rows = g.Kn > g.KP ? g.Kn : g.KP;
+    const size_t mix_bytes = (size_t)mix_rows * 2 * sizeof(float4);
+    if (g.mhat && (kind != 0 || g.LP % 128 || g.T < 1 || g.T > 4 || mix_rows > MIX_ROWS_MAX)) return (int)hipErrorInvalidValue;
     static int slots = 0;              // two workgroups per CU (LDS and registers), persistent over the tiles
     if (!slots) {
         int dev = 0, cus = 0;
@@ -319,8 +321,8 @@ int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
     dim3 grid((unsigned)(units < slots ? units : slots));
     static bool d0 = false, d1 = false, d2 = false, d3 = false;
     if (g.mhat) {
-        if (int e = set_lds(dft_rx3_kernel<0, true>, d3, LDS_BYTES + MIX_BYTES)) return e;
-        hipLaunchKernelGGL((dft_rx3_kernel<0, true>), grid, dim3(256), LDS_BYTES + MIX_BYTES, stream, a);
+        if (int e = set_lds(dft_rx3_kernel<0, true>, d3, LDS_BYTES + (size_t)MIX_ROWS_MAX * 2 * sizeof(float4))) return e;
+        hipLaunchKernelGGL((dft_rx3_kernel<0, true>), grid, dim3(256), LDS_BYTES + mix_bytes, stream, a);
     } else if (kind == 0) {
         if (int e = set_lds(dft_rx3_kernel<0, false>, d0, LDS_BYTES)) return e;
         hipLaunchKernelGGL((dft_rx3_kernel<0, false>), grid, dim3(256), LDS_BYTES, stream, a);
@@ -332,4 +334,12 @@ int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
         hipLaunchKernelGGL((dft_rx3_kernel<2, false>), grid, dim3(256), LDS_BYTES, stream, a);
     }
     return (int)hipGetLastError();
+}
+
+// whether every pass of the 2-D transforms of an [NBP][NAP][LP] cube / [2][NAP][KBP][LP] spectrum fits the kernel's
+// 32-bit lane offsets (plan creation falls back to the fp32 folded kernels otherwise)
+bool dft_rx3_supported(int Na, int Nb, long NAP, long KBP, long LP) {
+    const double rows = (double)((Na > Nb ? Na : Nb) + 17);
+    const double pitch = (double)(NAP > KBP ? NAP : KBP) * (double)LP * 4.0;      // largest row pitch of any pass (bytes)
+    return rows * pitch + 1024.0 < 4294967296.0 && (Na > Nb ? Na : Nb) <= MIX_ROWS_MAX;
 }

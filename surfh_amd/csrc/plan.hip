@@ -1085,6 +1085,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             return bail(1);
         const char *e5 = getenv("SURFH_DFT_RX3");
         p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
+        if (p->rx3 && !dft_rx3_supported(p->Na, p->Nb, p->NAP, p->KBP, p->LP)) p->rx3 = false;   // row pitch x rows beyond 4 GB
         {   // exact three-way bf16 split of the same matrices: x = h + m + l, |x - (h+m+l)| <= 2^-24 |x|
             std::vector<unsigned short> all;
             size_t off[6];

@@ -14,8 +14,7 @@ from oracle import surfh_oracle as orc
 pytestmark = pytest.mark.gpu
 
 
-def config2(Lc=1024):
-    N = 251
+def config2(Lc=1024, N=251):
     ax = orc.synthetic_axes(N, problems.STEP_DEG)
     wav = np.linspace(7.41, 8.87, Lc)
     spec = problems.band_spec("2a")
@@ -80,3 +79,24 @@ def test_config2_forward_parity_full_size(c2):
     e = rel(y, yo)
     print("config2 forward rel err", e, flush=True)
     assert e < 1e-5
+
+
+@pytest.mark.parametrize("N,Lc", [(300, 96), (501, 64)], ids=["even_300", "driver_default_501"])
+def test_other_image_sizes(N, Lc):
+    """Image sizes other than the benchmark's 251: an even size with two row tiles per DFT pass (N/2+1 = 151 > 128) and
+    the reference driver's default npix = 501 (scripts/main_fusion.py:213).  Forward / adjoint parity and the dot test."""
+    cfg = config2(Lc=Lc, N=N)
+    m = build_model(cfg, with_ref=False)
+    om = problems.oracle_model(cfg, box="direct")
+    rng = np.random.default_rng(8)
+    try:
+        y = m.forward(cfg["maps"])
+        ef = rel(y, om.forward(cfg["maps"]))
+        u = rng.random(y.shape)
+        ea = rel(m.adjoint(u), om.adjoint(u))
+        v = rng.random(m.ishape)
+        l = float(np.vdot(m.adjoint(u), v)); r = float(np.vdot(u, m.forward(v)))
+        print(f"N={N} Lc={Lc}: forward {ef:.2e} adjoint {ea:.2e} dot gap {abs(l - r) / abs(r):.2e}", flush=True)
+        assert ef < 1e-5 and ea < 1e-5 and abs(l - r) / abs(r) < 1e-6
+    finally:
+        m.close()
