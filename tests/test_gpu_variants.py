@@ -125,3 +125,38 @@ def test_explicit_inverse_solver_vs_reference():
         QuadCriterion3(y, m2, 0.0).run_expsol()
     m.close()
     m2.close()
+
+
+def _variant_problem(n_alpha, n_beta, n_templates, Lc=96):
+    """A config-1-like problem on a rectangular image with `n_templates` abundance maps."""
+    rng = np.random.default_rng(31)
+    ax_a = orc.synthetic_axes(n_alpha, problems.STEP_DEG)
+    ax_b = orc.synthetic_axes(n_beta, problems.STEP_DEG)
+    wav = np.linspace(7.50, 7.70, Lc)
+    spec = orc.ChannelSpec(0.8 / 3600, 0.9 / 3600, (0.0, 0.0), 8.2, 0.196, 4, 3050.0, np.linspace(7.53, 7.67, 40), "S1")
+    tpl = rng.random((n_templates, Lc)) + 0.5
+    sotf = orc.ir2fr(orc.gaussian_psf(wav, problems.STEP), (n_alpha, n_beta))
+    pts = orc.dither4(spec.det_pix_size, spec.beta_width / spec.n_slit)
+    return dict(N=n_alpha, Lc=Lc, alpha_axis=ax_a, beta_axis=ax_b, wavel=wav, specs=[spec], templates=tpl, sotf=sotf,
+                pointings=[pts], maps=rng.random((n_templates, n_alpha, n_beta)), step_deg=problems.STEP_DEG)
+
+
+@pytest.mark.parametrize("na,nb,T", [(72, 64, 4), (64, 80, 6), (66, 66, 1)], ids=["rect_72x64", "rect_64x80_T6", "one_template"])
+def test_rectangular_images_and_template_counts(na, nb, T):
+    """Image axes of different lengths and template counts other than 4 (the reference driver also runs with 6:
+    scripts/main_fusion.py:88-93; more than 4 templates take the un-fused spectral mix)."""
+    cfg = _variant_problem(na, nb, T)
+    om = problems.oracle_model(cfg, box="direct")
+    m = build_model(cfg)
+    rng = np.random.default_rng(2)
+    try:
+        assert m.ishape == (T, na, nb)
+        y = m.forward(cfg["maps"])
+        u = rng.random(y.shape)
+        e = dict(fwd=rel(y, om.forward(cfg["maps"])), adj=rel(m.adjoint(u), om.adjoint(u)))
+        print(na, nb, T, e)
+        assert max(e.values()) < TOL
+        x, gn, nit = m.cg(y, mu=1.0, mu_reg=10.0, max_iter=5)
+        assert nit == 5 and gn[-1] < gn[0] and x.shape == (T, na, nb)
+    finally:
+        m.close()
