@@ -3,6 +3,7 @@
 // row with its mirror row on the fly, the K loop runs two phases into two accumulator sets, and
 // the epilogue writes the (r, N-r) output pair from their sum / difference.
 #include "dft_fold.h"
+#include "lds_attr.h"
 
 #include <cstdlib>
 
@@ -405,12 +406,8 @@ int launch_dft_fold4(hipStream_t stream, const DftFold4Args &g) {
     if (g.MP % BM || g.KP % BK || g.N % BN4 || g.batch < 1) return (int)hipErrorInvalidValue;
     if (g.mhat && (g.LP % BN4 || g.T < 1)) return (int)hipErrorInvalidValue;
     const size_t lds_bytes = (size_t)2 * BUF4_FLOATS * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)dft_fold4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int e = ensure_dynamic_lds(dft_fold4_kernel, lds_bytes, attr_done)) return e;
     dim3 grid(g.N / BN4, g.MP / BM, g.batch);
     hipLaunchKernelGGL(dft_fold4_kernel, grid, dim3(256), lds_bytes, stream, g);
     return (int)hipGetLastError();
@@ -426,12 +423,8 @@ int launch_dft_fold(hipStream_t stream, const DftFoldArgs &g) {
     const char *env = getenv("SURFH_FOLD_TWO_PHASE");
     if ((eo || two) && !(env && env[0] == '1')) {
         const size_t lds_bytes = (size_t)2 * D2_BUF * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute((const void *)dft_dual_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
-            if (e != hipSuccess) return (int)e;
-            attr_set = true;
-        }
+        static unsigned long long attr_done = 0;
+        if (int e = ensure_dynamic_lds(dft_dual_kernel, lds_bytes, attr_done)) return e;
         hipLaunchKernelGGL(dft_dual_kernel, grid, dim3(256), lds_bytes, stream, g);
         return (int)hipGetLastError();
     }

@@ -4,6 +4,7 @@
 // are double-buffered in LDS, filled by LDS-DMA into an XOR-swizzled image: each A fragment is one conflict-free
 // ds_read_b128.  Workgroups are persistent (two per CU) and pipeline loads / MFMAs / stores across tile seams.
 #include "dft_rx3.h"
+#include "lds_attr.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -285,15 +286,6 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
 #undef RX_MFMA
 }
 
-template <typename K>
-int set_lds(K kernel, bool &done, size_t bytes) {
-    if (done) return 0;
-    hipError_t e = hipFuncSetAttribute((const void *)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e != hipSuccess) return (int)e;
-    done = true;
-    return 0;
-}
-
 }  // namespace
 
 int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
@@ -307,30 +299,33 @@ int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
     const int mix_rows = g.Kn > g.KP ? g.Kn : g.KP;
     const size_t mix_bytes = (size_t)mix_rows * 2 * sizeof(float4);
     if (g.mhat && (kind != 0 || g.LP % 128 || g.T < 1 || g.T > 4 || mix_rows > MIX_ROWS_MAX)) return (int)hipErrorInvalidValue;
-    static int slots = 0;              // two workgroups per CU (LDS and registers), persistent over the tiles
-    if (!slots) {
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
-        slots = 2 * cus;
+    static int slots_of[64] = {0};     // two workgroups per CU (LDS and registers), persistent over the tiles
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    if (!slots_of[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+        slots_of[dev] = 2 * cus;
     }
+    const int slots = slots_of[dev];
     if (g.nvar != 1 && (g.nvar != 2 || g.mode != 0 || !g.dst_alt || !g.A_alt[0] || !g.A_alt[1])) return (int)hipErrorInvalidValue;
     const long ntile = (long)(g.N / 128) * (g.MP / 128) * g.batch;
     DftRx3Args a = g;
     a.strided = (ntile < slots) ? 1 : 0;
     const long units = a.strided ? ntile * g.nvar : ntile;
     dim3 grid((unsigned)(units < slots ? units : slots));
-    static bool d0 = false, d1 = false, d2 = false, d3 = false;
+    static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
     if (g.mhat) {
-        if (int e = set_lds(dft_rx3_kernel<0, true>, d3, LDS_BYTES + (size_t)MIX_ROWS_MAX * 2 * sizeof(float4))) return e;
+        if (int e = ensure_dynamic_lds(dft_rx3_kernel<0, true>, LDS_BYTES + (size_t)MIX_ROWS_MAX * 2 * sizeof(float4), d3)) return e;
         hipLaunchKernelGGL((dft_rx3_kernel<0, true>), grid, dim3(256), LDS_BYTES + mix_bytes, stream, a);
     } else if (kind == 0) {
-        if (int e = set_lds(dft_rx3_kernel<0, false>, d0, LDS_BYTES)) return e;
+        if (int e = ensure_dynamic_lds(dft_rx3_kernel<0, false>, LDS_BYTES, d0)) return e;
         hipLaunchKernelGGL((dft_rx3_kernel<0, false>), grid, dim3(256), LDS_BYTES, stream, a);
     } else if (kind == 1) {
-        if (int e = set_lds(dft_rx3_kernel<1, false>, d1, LDS_BYTES)) return e;
+        if (int e = ensure_dynamic_lds(dft_rx3_kernel<1, false>, LDS_BYTES, d1)) return e;
         hipLaunchKernelGGL((dft_rx3_kernel<1, false>), grid, dim3(256), LDS_BYTES, stream, a);
     } else {
-        if (int e = set_lds(dft_rx3_kernel<2, false>, d2, LDS_BYTES)) return e;
+        if (int e = ensure_dynamic_lds(dft_rx3_kernel<2, false>, LDS_BYTES, d2)) return e;
         hipLaunchKernelGGL((dft_rx3_kernel<2, false>), grid, dim3(256), LDS_BYTES, stream, a);
     }
     return (int)hipGetLastError();

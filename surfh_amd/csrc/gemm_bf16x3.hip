@@ -11,6 +11,7 @@
 // Operand maps of v_mfma_f32_32x32x16_bf16 (lane l, r = l&31, h = l>>5):
 //   A fragment: A[row r][k = 8h + j], j = 0..7 ;  B fragment: B[k = 8h + j][col r] ;  D as the fp32 forms.
 #include "gemm_f32.h"
+#include "lds_attr.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -139,12 +140,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_bf16x3_kernel(GemmArgs g) {
 // C[M][N] = A[M][K] * B[N][K]^T ; M, N multiples of 128, K of 16*splitK.  GemmArgs.B0/ldb describe B as [N][K].
 int launch_gemm_nt_bf16x3(hipStream_t stream, const GemmArgs &g) {
     if (g.M % BM || g.N % BN || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1 || g.accumulate) return (int)hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)gemm_nt_bf16x3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int e = ensure_dynamic_lds(gemm_nt_bf16x3_kernel, LDS_BYTES, attr_done)) return e;
     dim3 grid((g.M / BM) * (g.N / BN), 1, g.batch * g.splitK);
     hipLaunchKernelGGL(gemm_nt_bf16x3_kernel, grid, dim3(256), LDS_BYTES, stream, g);
     return (int)hipGetLastError();

@@ -19,6 +19,7 @@
 // tools/exp/gemm_bias_main.hip: +3e-8 for chains of <= 1024 k, -1.4e-6 at 1536 k, -7.7e-6 at 3072 k, -1.7e-5 at 12288 k
 // (the fp32-input MFMA has none).  Callers therefore keep K / splitK at about 1024 (plan.hip:pick_split).
 #include "gemm_f32.h"
+#include "lds_attr.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -188,12 +189,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16x3_pc_kernel(GemmArgs g) {
 int launch_gemm_nt_bf16x3_pc(hipStream_t stream, const GemmArgs &g) {
     if (g.M % BM || g.N % 128 || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1 || g.accumulate || g.lda % 4 || g.ldb % 4)
         return (int)hipErrorInvalidValue;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)gemm_nt_bf16x3_pc_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_BYTES);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    static unsigned long long attr_done = 0;
+    if (int e = ensure_dynamic_lds(gemm_nt_bf16x3_pc_kernel, LDS_BYTES, attr_done)) return e;
     if ((double)(BM + 1) * (double)g.ldc * 4.0 >= 2147483648.0) return (int)hipErrorInvalidValue;
     const long total = (long)(g.M / BM) * ((g.N + BN - 1) / BN) * g.batch * g.splitK;
     dim3 grid((unsigned)(8 * ((total + 7) / 8)));
