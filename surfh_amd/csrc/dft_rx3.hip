@@ -58,6 +58,7 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
     const int tilesX = g.N / 128, tilesY = g.MP / 128;
     const int ntile = tilesX * tilesY * g.batch * g.nvar;     // units: (tile, variant), variant fastest
     const unsigned ldb4 = (unsigned)(g.ldb * 4), ldc4 = (unsigned)(g.ldc * 4), c4 = (unsigned)(wave * 32 + l31) * 4u;
+    const long ldbB = g.ldb * 4, ldcB = g.ldc * 4;
     const int nk = g.KP / BK;
     const int kin = g.Kn / 2 + 1;
     const int arow = tid >> 1;                                 // = 32 * wave + (lane >> 1)
@@ -115,18 +116,19 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
     // all of them are in flight together
 #define RX_BLOAD(kt_)                                                                                           \
     {                                                                                                           \
-        const unsigned ok = ((kt_) * BK + 8 * hv) * ldb4 + c4;                                                   \
-        const unsigned op = (g.Kn - (kt_) * BK - 8 * hv) * ldb4 + c4;                                            \
+        /* row part of every address in 64-bit scalar pointers, lane part (k half and column) in one small VGPR: no  \
+           limit on the array size.  Mirror row of k = 16 kt + 8 h + j is (Kn - 16 kt - 8 - j) + 8 (1 - h); it is read  \
+           unconditionally (its weight is zero where there is no mirror), except k = 0 whose "mirror" Kn may not exist */ \
+        const char *rk0 = B0 + (long)((kt_) * BK) * ldbB, *rk1 = B1 + (long)((kt_) * BK) * ldbB;                 \
+        const char *rp0 = B0 + (long)(g.Kn - (kt_) * BK - 8) * ldbB, *rp1 = B1 + (long)(g.Kn - (kt_) * BK - 8) * ldbB; \
+        const unsigned vk = (unsigned)(8 * hv) * ldb4 + c4, vp = (unsigned)(8 * (1 - hv)) * ldb4 + c4;           \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
-            const int k = (kt_) * BK + 8 * hv + j;                                                               \
-            const unsigned o = ok + j * ldb4;                                                                   \
-            xr[j] = *reinterpret_cast<const float *>(B0 + o);                                                   \
-            if (KIND != 1) xi[j] = *reinterpret_cast<const float *>(B1 + o);                                    \
+            xr[j] = *reinterpret_cast<const float *>(rk0 + j * ldbB + vk);                                      \
+            if (KIND != 1) xi[j] = *reinterpret_cast<const float *>(rk1 + j * ldbB + vk);                       \
             if (KIND != 2) {                                                                                    \
-                const bool pv = (k >= 1) && (k < kin) && (2 * k != g.Kn);                                       \
-                const unsigned q = pv ? op - j * ldb4 : o;                                                      \
-                qr[j] = *reinterpret_cast<const float *>(B0 + q);                                               \
-                if (KIND != 1) qi[j] = *reinterpret_cast<const float *>(B1 + q);                                \
+                const unsigned q = (j == 0 && (kt_) == 0) ? c4 : vp;                                            \
+                qr[j] = *reinterpret_cast<const float *>(rp0 - j * ldbB + q);                                   \
+                if (KIND != 1) qi[j] = *reinterpret_cast<const float *>(rp1 - j * ldbB + q);                    \
             }                                                                                                   \
         }                                                                                                       \
     }
@@ -235,9 +237,10 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
         char *D0 = reinterpret_cast<char *>((ealt ? g.dst_alt : g.dst[0]) + bz * g.sC + n0);
         char *D1 = reinterpret_cast<char *>((g.dst[1] ? g.dst[1] : g.dst[0]) + bz * g.sC + n0);
         const int em0 = m0;
-        unsigned vo = c4 + (unsigned)(em0 + 4 * h) * ldc4;
-        unsigned vm = c4 + (unsigned)(g.Rn - em0 - 4 * h) * ldc4;
-        asm volatile("" : "+v"(vo), "+v"(vm));
+        // row (em0 + rr + 4 h) through a running scalar pointer + the lane's (4 h, column) offset; mirror row
+        // Rn - row = (Rn - em0 - 4 - rr) + 4 (1 - h) likewise
+        char *Dk0 = D0 + (long)em0 * ldcB, *Dk1 = D1 + (long)em0 * ldcB, *Dm0 = D0 + (long)(g.Rn - em0 - 4) * ldcB;
+        const unsigned lo = (unsigned)(4 * h) * ldc4 + c4, lm = (unsigned)(4 * (1 - h)) * ldc4 + c4;
         const int next = g.strided ? tile + (int)gridDim.x
                                    : (((tile % g.nvar) + 1 < g.nvar) ? tile + 1 : tile + 1 + ((int)gridDim.x - 1) * g.nvar);
         const bool more = next < ntile;
@@ -248,8 +251,7 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
         }
         RX_MFMA(buf);
         {
-            unsigned oo = vo, om = vm;     // running offsets of row (em0 + rr + 4h) and of its mirror row
-            const unsigned s1 = ldc4, s5 = 5u * ldc4;
+            const long s1 = ldcB, s5 = 5 * ldcB;
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -258,15 +260,15 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
                     const float a1 = acc1[mt][r], a2 = acc2[mt][r];
                     if (row < g.rvalid) {
                         if (g.mode == 0) {
-                            *reinterpret_cast<float *>(D0 + oo) = e00 * a1 + e01 * a2;
-                            if (row >= 1 && 2 * row != g.Rn) *reinterpret_cast<float *>(D0 + om) = e10 * a1 + e11 * a2;
+                            *reinterpret_cast<float *>(Dk0 + lo) = e00 * a1 + e01 * a2;
+                            if (row >= 1 && 2 * row != g.Rn) *reinterpret_cast<float *>(Dm0 + lm) = e10 * a1 + e11 * a2;
                         } else {
-                            *reinterpret_cast<float *>(D0 + oo) = e00 * a1;
-                            *reinterpret_cast<float *>(D1 + oo) = e11 * a2;
+                            *reinterpret_cast<float *>(Dk0 + lo) = e00 * a1;
+                            *reinterpret_cast<float *>(Dk1 + lo) = e11 * a2;
                         }
                     }
-                    oo += ((r & 3) == 3) ? s5 : s1;
-                    om -= ((r & 3) == 3) ? s5 : s1;
+                    const long st = ((r & 3) == 3) ? s5 : s1;
+                    Dk0 += st; Dk1 += st; Dm0 -= st;
                 }
         }
         if (!more) break;
@@ -291,9 +293,8 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
 int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
     if (g.MP % 128 || g.KP % BK || g.N % 128 || g.batch < 1) return (int)hipErrorInvalidValue;
     if (g.mode == 1 && !g.dst[1]) return (int)hipErrorInvalidValue;
-    // lane offsets are unsigned 32-bit relative to the tile's base: all rows of a tile column must lie within 4 GB
-    if ((double)(g.Kn > g.KP ? g.Kn + 1 : g.KP) * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
-    if ((double)((g.mode == 0 ? g.Rn : g.rvalid) + 1) * (double)g.ldc * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
+    // the lane part of an address is 8 rows + a column inside the tile (32-bit); rows go through 64-bit scalar pointers
+    if (8.0 * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0 || 4.0 * (double)g.ldc * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
     const bool folded = g.fold[0] != 0.f || g.fold[1] != 0.f || (g.nvar == 2 && (g.fold_alt[0] != 0.f || g.fold_alt[1] != 0.f));
     const int kind = !folded ? 2 : (g.src[0] == g.src[1] ? 1 : 0);
     const int mix_rows = g.Kn > g.KP ? g.Kn : g.KP;
@@ -331,10 +332,10 @@ int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
     return (int)hipGetLastError();
 }
 
-// whether every pass of the 2-D transforms of an [NBP][NAP][LP] cube / [2][NAP][KBP][LP] spectrum fits the kernel's
-// 32-bit lane offsets (plan creation falls back to the fp32 folded kernels otherwise)
+// whether the kernel can run the 2-D transforms of an [NBP][NAP][LP] cube / [2][NAP][KBP][LP] spectrum (plan creation
+// falls back to the fp32 folded kernels otherwise): eight row pitches must fit a 32-bit lane offset, the spectral-mix
+// table must fit LDS
 bool dft_rx3_supported(int Na, int Nb, long NAP, long KBP, long LP) {
-    const double rows = (double)((Na > Nb ? Na : Nb) + 17);
     const double pitch = (double)(NAP > KBP ? NAP : KBP) * (double)LP * 4.0;      // largest row pitch of any pass (bytes)
-    return rows * pitch + 1024.0 < 4294967296.0 && (Na > Nb ? Na : Nb) <= MIX_ROWS_MAX;
+    return 8.0 * pitch + 1024.0 < 4294967296.0 && (Na > Nb ? Na : Nb) <= MIX_ROWS_MAX;
 }
