@@ -169,6 +169,19 @@ int surfh_debug_dims(surfh_plan *plan, const char *which, int64_t dims[4]);
 int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split_k,
                         const float *A, const float *B, float *C);
 
+/* ---- masked linear mixing model (MixingST, surfh/Models/mixing.py:276-337; kernels c_fast_forward_TST,
+ * c_fast_adjoint_TST, c_precompute_TST of surfh/ToolsDir/cythons_files.pyx:370-463) ----
+ * voxels: [n_voxels][3] (lambda, i, j) as `fast_selection_arr`; S: [Lc][Na][Nb] float mask for fwadj's TST
+ * (ones with zeros at `selection_arr`, mixing.py:320-321) or NULL.  templates are cast to float32 like the reference. */
+typedef struct surfh_tst surfh_tst;
+int surfh_tst_create(int32_t n_alpha, int32_t n_beta, int32_t n_lambda, int32_t n_templates, const double *templates,
+                     const int32_t *voxels, int64_t n_voxels, const float *S, int32_t device, surfh_tst **out);
+int surfh_tst_destroy(surfh_tst *t);
+int surfh_tst_forward(surfh_tst *t, const float *maps, float *cube);     /* mixing.py:301-306 */
+int surfh_tst_adjoint(surfh_tst *t, const float *cube, float *maps);     /* mixing.py:308-313 */
+int surfh_tst_fwadj(surfh_tst *t, const float *maps, float *out);        /* mixing.py:316-317 */
+const char *surfh_tst_last_error(void);
+
 #ifdef __cplusplus
 }
 #endif

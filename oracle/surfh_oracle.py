@@ -845,3 +845,36 @@ def reg_freq(shape, gradient="separated"):
         lap = np.array([[0.0, -1.0, 0.0], [-1.0, 4.0, -1.0], [0.0, -1.0, 0.0]])
         return np.abs(ir2fr(lap, shape)) ** 2
     raise ValueError(gradient)
+
+
+# ----------------------------------------------------------------------------
+# Masked linear mixing model (surfh/Models/mixing.py:276-337 + cythons_files.pyx:370-463), float32 like the reference
+# ----------------------------------------------------------------------------
+class MixingSTOracle:
+    def __init__(self, templates, shape, selection_arr, fast_selection_arr):
+        self.tpl = np.asarray(templates, dtype=np.float32)
+        self.shape = tuple(shape)                                   # (Na, Nb)
+        self.vox = np.asarray(fast_selection_arr).reshape(-1, 3)
+        L = self.tpl.shape[1]
+        S = np.ones((L,) + self.shape, dtype=np.float32)
+        S[selection_arr] = 0
+        # c_precompute_TST (:374-392)
+        self.TST = np.einsum("pl,ml,lij->mpij", self.tpl.astype(np.float64), self.tpl.astype(np.float64), S.astype(np.float64))
+
+    def forward(self, maps):                                        # c_fast_forward_TST (:400-417)
+        maps = np.asarray(maps, dtype=np.float32)
+        cube = np.zeros((self.tpl.shape[1],) + self.shape, dtype=np.float64)
+        l, i, j = self.vox[:, 0], self.vox[:, 1], self.vox[:, 2]
+        np.add.at(cube, (l, i, j), np.einsum("mv,mv->v", maps[:, i, j].astype(np.float64), self.tpl[:, l].astype(np.float64)))
+        return cube
+
+    def adjoint(self, cube):                                        # c_fast_adjoint_TST (:447-463)
+        cube = np.asarray(cube, dtype=np.float32)
+        maps = np.zeros((self.tpl.shape[0],) + self.shape, dtype=np.float64)
+        l, i, j = self.vox[:, 0], self.vox[:, 1], self.vox[:, 2]
+        for m in range(self.tpl.shape[0]):
+            np.add.at(maps[m], (i, j), cube[l, i, j].astype(np.float64) * self.tpl[m, l])
+        return maps
+
+    def fwadj(self, maps):                                          # mixing.py:316-317
+        return np.sum(self.TST * np.asarray(maps, dtype=np.float64)[np.newaxis], axis=1)

@@ -122,3 +122,66 @@ class QuadCriterion3:
         if self.printing:
             print("Total time needed for expsol = {} sec.".format(round(time.time() - t1, 3)))
         return res
+
+
+class MixingST(LinOp):
+    """Masked linear mixing model (surfh/Models/mixing.py:276-337): the cube exists only on the voxels of
+    ``fast_selection_arr`` (``[n, 3]`` rows ``(lambda, i, j)``, e.g. ``np.array(np.where(y_cube > 1e-5)).T``);
+    ``selection_arr`` is the complementary NumPy index (``np.where(y_cube < 1e-5)``) whose voxels are zeroed in the
+    mask ``S`` behind ``fwadj``'s ``TST``.  Same constructor as the reference; float32 arithmetic like its Cython
+    kernels (cythons_files.pyx:370-463)."""
+
+    def __init__(self, templates, alpha_axis, beta_axis, wavel_axis, selection_arr, fast_selection_arr,
+                 dtype=np.float64, *, device: int = 0):
+        self.templates = np.ascontiguousarray(templates, dtype=np.float64)
+        self.alpha_axis, self.beta_axis, self.wavel_axis = alpha_axis, beta_axis, wavel_axis
+        self.selection_arr, self.fast_selection_arr = selection_arr, fast_selection_arr
+        T, L, na, nb = self.templates.shape[0], len(wavel_axis), len(alpha_axis), len(beta_axis)
+        if self.templates.shape[1] != L:
+            raise ValueError("templates must be [n_maps, len(wavel_axis)]")
+        super().__init__((T, na, nb), (L, na, nb), "MixingModelST", dtype)
+        vox = np.ascontiguousarray(np.asarray(fast_selection_arr).reshape(-1, 3), dtype=np.int32)
+        S = None
+        if selection_arr is not None:                              # fast_precompute_TST, mixing.py:319-327
+            S = np.ones((L, na, nb), dtype=np.float32)
+            S[selection_arr] = 0
+        lib = _lib.load()
+        h = C.c_void_p()
+        rc = lib.surfh_tst_create(na, nb, L, T, _lib.dptr(self.templates), vox.ctypes.data_as(_lib.c_int32_p), vox.shape[0],
+                                  _lib.fptr(S) if S is not None else None, device, C.byref(h))
+        if rc:
+            raise ValueError(lib.surfh_tst_last_error().decode())
+        self._L, self._h = lib, h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.surfh_tst_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _run(self, fn, x, shape_in, shape_out):
+        if tuple(np.shape(x)) != tuple(shape_in):
+            raise ValueError(f"expected shape {tuple(shape_in)}, got {tuple(np.shape(x))}")
+        a = np.ascontiguousarray(np.asarray(x, dtype=np.float32).reshape(-1))
+        out = np.empty(int(np.prod(shape_out)), dtype=np.float32)
+        if fn(self._h, _lib.fptr(a), _lib.fptr(out)):
+            raise RuntimeError(self._L.surfh_tst_last_error().decode())
+        return out.reshape(shape_out)
+
+    def forward(self, maps):
+        return self._run(self._L.surfh_tst_forward, maps, self.ishape, self.oshape)
+
+    def adjoint(self, cube):
+        return self._run(self._L.surfh_tst_adjoint, cube, self.oshape, self.ishape)
+
+    def fwadj(self, maps):
+        return self._run(self._L.surfh_tst_fwadj, maps, self.ishape, self.ishape)
+
+    def mapsToCube(self, maps):
+        """Unmasked LMM (mixing.py:330-334)."""
+        return np.sum(np.expand_dims(np.asarray(maps), 1) * self.templates[..., np.newaxis, np.newaxis], axis=0)

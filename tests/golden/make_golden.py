@@ -236,7 +236,29 @@ def wct():
                         mu_list=np.array(mu_list))
 
 
+def mixing_st_inputs():
+    rng = np.random.default_rng(23)
+    L, T, na, nb = 24, 3, 20, 18
+    tpl = rng.random((T, L)) + 0.25
+    y_cube = rng.random((L, na, nb)) * (rng.random((L, na, nb)) > 0.6)      # 60 % of the voxels are empty
+    selection_arr = np.where(y_cube < 1e-5)
+    fast_selection_arr = np.array(np.where(y_cube > 1e-5)).T                # as scripts/fusion/test_mixing_ST.py:117-118
+    maps = rng.random((T, na, nb))
+    cube = rng.standard_normal((L, na, nb))
+    return tpl, (na, nb), L, selection_arr, fast_selection_arr, maps, cube
+
+
+def mixing_st():
+    """MixingST (surfh/Models/mixing.py:276-337) through the reference's compiled Cython kernels."""
+    ns = rh.load()
+    tpl, (na, nb), L, sel, fast, maps, cube = mixing_st_inputs()
+    m = ns.mixing().MixingST(tpl, np.arange(na, dtype=float), np.arange(nb, dtype=float), np.arange(L, dtype=float), sel, fast)
+    np.savez_compressed(os.path.join(HERE, "mixing_st.npz"), forward=m.forward(maps), adjoint=m.adjoint(cube), fwadj=m.fwadj(maps),
+                        TST=np.asarray(m.TST))
+
+
 if __name__ == "__main__":
     main()
     blurred()
     wct()
+    mixing_st()

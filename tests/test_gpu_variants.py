@@ -160,3 +160,34 @@ def test_rectangular_images_and_template_counts(na, nb, T):
         assert nit == 5 and gn[-1] < gn[0] and x.shape == (T, na, nb)
     finally:
         m.close()
+
+
+def test_masked_mixing_model_vs_reference():
+    """MixingST (mixing.py:276-337) against the outputs of the reference's own Cython kernels."""
+    from surfh_amd.mixing import MixingST
+    src = open(os.path.join(G, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("def mixing_st_inputs"):src.index("def mixing_st():")], {"np": np}, ns)
+    tpl, (na, nb), L, sel, fast, maps, cube = ns["mixing_st_inputs"]()
+    g = np.load(os.path.join(G, "mixing_st.npz"))
+    m = MixingST(tpl, np.arange(na, dtype=float), np.arange(nb, dtype=float), np.arange(L, dtype=float), sel, fast)
+    assert m.ishape == (3, na, nb) and m.oshape == (L, na, nb)
+    e = dict(fwd=rel(m.forward(maps), g["forward"]), adj=rel(m.adjoint(cube), g["adjoint"]), fwadj=rel(m.fwadj(maps), g["fwadj"]))
+    print(e)
+    assert max(e.values()) < 1e-6
+    assert np.array_equal(m.forward(maps) == 0, g["forward"] == 0)
+    assert rel(m.mapsToCube(maps), np.tensordot(tpl.T, maps, axes=(1, 0))) < 1e-12
+    # a voxel listed twice counts twice (the reference's +=); an empty list gives zeros
+    dup = np.concatenate([fast, fast[:50]])
+    m2 = MixingST(tpl, np.arange(na, dtype=float), np.arange(nb, dtype=float), np.arange(L, dtype=float), None, dup)
+    f1, f2 = m.forward(maps), m2.forward(maps)
+    idx = tuple(fast[:50].T)
+    assert np.allclose(f2[idx], 2 * f1[idx], rtol=1e-6) and rel(m2.adjoint(cube), m.adjoint(cube) + orc.MixingSTOracle(tpl, (na, nb), sel, fast[:50]).adjoint(cube)) < 1e-6
+    with pytest.raises(RuntimeError):
+        m2.fwadj(maps)                                      # no mask given -> no TST
+    m3 = MixingST(tpl, np.arange(na, dtype=float), np.arange(nb, dtype=float), np.arange(L, dtype=float), sel, np.zeros((0, 3), dtype=int))
+    assert not m3.forward(maps).any() and not m3.adjoint(cube).any()
+    with pytest.raises(ValueError):
+        MixingST(tpl, np.arange(na, dtype=float), np.arange(nb, dtype=float), np.arange(L, dtype=float), sel, np.array([[L, 0, 0]]))
+    for mm in (m, m2, m3):
+        mm.close()

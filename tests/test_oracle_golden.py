@@ -216,3 +216,20 @@ def test_model_wct_oracle_vs_reference():
     xs = wo.expsol(y, 0.7)
     lhs = wo.fwadj(xs) + 0.7 * (orc.diff_r_t(orc.diff_r(xs)) + orc.diff_c_t(orc.diff_c(xs)))
     assert rel(lhs, wo.adjoint(y)) < 1e-12
+
+
+def test_mixing_st_oracle_vs_reference():
+    """MixingSTOracle against the reference's MixingST run through its compiled Cython kernels
+    (tests/golden/mixing_st.npz; float32 there, float64 here)."""
+    src = open(os.path.join(G, "make_golden.py")).read()
+    ns = {}
+    exec(src[src.index("def mixing_st_inputs"):src.index("def mixing_st():")], {"np": np}, ns)
+    tpl, shape, L, sel, fast, maps, cube = ns["mixing_st_inputs"]()
+    g = np.load(os.path.join(G, "mixing_st.npz"))
+    o = orc.MixingSTOracle(tpl, shape, sel, fast)
+    assert rel(o.forward(maps), g["forward"]) < 2e-7
+    assert rel(o.adjoint(cube), g["adjoint"]) < 2e-7
+    assert rel(o.fwadj(maps), g["fwadj"]) < 2e-7 and rel(o.TST, g["TST"]) < 2e-7
+    assert np.array_equal(g["forward"] == 0, o.forward(maps) == 0)          # same support
+    # adjointness of the masked pair (inputs are rounded to float32 like the reference's kernels)
+    assert abs(np.vdot(o.forward(maps), cube) - np.vdot(maps, o.adjoint(cube))) < 1e-6 * abs(np.vdot(maps, o.adjoint(cube)))
