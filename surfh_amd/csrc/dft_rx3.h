@@ -35,6 +35,10 @@ struct DftRx3Args {
     // output components of a complex pass -- so that the second read of the tile comes from the caches, not HBM
     int nvar = 1;
     int strided = 0;                           // set by the launcher
+    // packed = 1 (with nvar = 2): both variants in ONE pass over 64-column tiles -- lanes 0-15 of a half-wave carry
+    // the columns with the first variant's fold, lanes 16-31 the same columns with the second variant's, so the tile is
+    // read once; needs 0 <= (dst_alt - dst[0]) * 4 < 2^31 (the launcher falls back to the two-pass form otherwise)
+    int packed = 0;
     const unsigned short *A_alt[2] = {nullptr, nullptr};
     float fold_alt[2] = {0.f, 0.f};
     float *dst_alt = nullptr;                  // PAIR only

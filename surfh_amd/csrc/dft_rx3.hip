@@ -55,9 +55,13 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
-    const int tilesX = g.N / 128, tilesY = g.MP / 128;
-    const int ntile = tilesX * tilesY * g.batch * g.nvar;     // units: (tile, variant), variant fastest
-    const unsigned ldb4 = (unsigned)(g.ldb * 4), ldc4 = (unsigned)(g.ldc * 4), c4 = (unsigned)(wave * 32 + l31) * 4u;
+    const bool packed = (KIND == 0) && g.packed;
+    const int TN = packed ? 64 : 128;                          // columns of a tile
+    const int var = packed ? (l31 >> 4) : 0;                   // packed: which variant this lane's column copy carries
+    const int lcol = packed ? wave * 16 + (l31 & 15) : wave * 32 + l31;
+    const int tilesX = g.N / TN, tilesY = g.MP / 128;
+    const int ntile = tilesX * tilesY * g.batch * (packed ? 1 : g.nvar);     // units: (tile, variant), variant fastest
+    const unsigned ldb4 = (unsigned)(g.ldb * 4), ldc4 = (unsigned)(g.ldc * 4), c4 = (unsigned)lcol * 4u;
     const long ldbB = g.ldb * 4, ldcB = g.ldc * 4;
     const int nk = g.KP / BK;
     const int kin = g.Kn / 2 + 1;
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
     // k-step's matrix work and the epilogue stores of the current tile, so that loads, stores and MFMAs overlap.
     // unit id = tile index * nvar + variant.  Large launches: a workgroup does all variants of its tiles back to back;
     // launches with fewer tiles than workgroup slots (`strided`): units are dealt one by one so every slot gets work
-    int tile = g.strided ? (int)blockIdx.x : (int)blockIdx.x * g.nvar;
+    int tile = (g.strided || packed) ? (int)blockIdx.x : (int)blockIdx.x * g.nvar;
     // per-tile state (uniform): uniform base + 32-bit lane offset addressing (the launcher checks that the rows fit
     // in 2^31 bytes): one scalar pair and one VGPR per address instead of 64-bit vector arithmetic
     const char *B0, *B1, *A0, *A1;
@@ -80,12 +84,12 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
     float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
 #define RX_SETUP(t_)                                                                                            \
     {                                                                                                           \
-        const int alt_ = (t_) % g.nvar, tt_ = (t_) / g.nvar;                                                    \
+        const int alt_ = packed ? 0 : (t_) % g.nvar, tt_ = packed ? (t_) : (t_) / g.nvar;                       \
         const int tx = tt_ % tilesX, ty = (tt_ / tilesX) % tilesY;                                              \
         bz = tt_ / (tilesX * tilesY);                                                                           \
         fo0 = alt_ ? g.fold_alt[0] : g.fold[0];                                                                 \
         fo1 = alt_ ? g.fold_alt[1] : g.fold[1];                                                                 \
-        n0 = tx * 128;                                                                                          \
+        n0 = tx * TN;                                                                                           \
         m0 = ty * 128;                                                                                          \
         B0 = reinterpret_cast<const char *>(g.src[0] + bz * g.sB + n0);                                         \
         B1 = reinterpret_cast<const char *>(g.src[1] + bz * g.sB + n0);                                         \
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
 #define RX_MIXTAB()                                                                                             \
     {                                                                                                           \
         const int kb = n0 / g.LP;                                                                               \
-        const int l = (n0 % g.LP) + wave * 32 + l31;                                                            \
+        const int l = (n0 % g.LP) + lcol;                                                                       \
         float t4[4];                                                                                            \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) t4[t] = (t < g.T) ? g.tpl[(long)t * g.LP + l] : 0.f;      \
         tw = make_float4(t4[0], t4[1], t4[2], t4[3]);                                                           \
@@ -161,10 +165,12 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
                     br = hr * sr - hi * si;                                                                     \
                     bi = hr * si + hi * sr;                                                                     \
                 }                                                                                               \
-                const float f0 = pv ? fo0 : 0.f, f1 = pv ? fo1 : 0.f;                                           \
-                const float w0 = (!pv && fo0 < 0.f) ? 0.f : 1.f, w1 = (!pv && fo1 < 0.f) ? 0.f : 1.f;           \
-                x0[j] = w0 * ar + f0 * br;                                                                      \
-                x1[j] = w1 * ai + f1 * bi;                                                                      \
+                const float g0 = var ? g.fold_alt[0] : fo0, g1 = var ? g.fold_alt[1] : fo1;                     \
+                const float f0 = pv ? g0 : 0.f, f1 = pv ? g1 : 0.f;                                             \
+                const float w0 = (!pv && g0 < 0.f) ? 0.f : 1.f, w1 = (!pv && g1 < 0.f) ? 0.f : 1.f;             \
+                const float s0 = w0 * ar + f0 * br, s1v = w1 * ai + f1 * bi;                                    \
+                x0[j] = var ? s1v : s0;       /* the second variant pairs its streams with the other matrix */   \
+                x1[j] = var ? s0 : s1v;                                                                         \
             }                                                                                                   \
         }                                                                                                       \
     }
@@ -231,17 +237,19 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
         // last k-step: where the next tile's first loads are issued
         // epilogue addressing: uniform base + 32-bit lane offset; the asm barrier keeps the (loop-invariant) row
         // offsets from being hoisted out of the persistent loop into a few hundred registers
-        const int ealt = tile % g.nvar;
-        const float e00 = ealt ? g.e_alt[0] : g.e00, e01 = ealt ? g.e_alt[1] : g.e01;
-        const float e10 = ealt ? g.e_alt[2] : g.e10, e11 = ealt ? g.e_alt[3] : g.e11;
+        const int ealt = packed ? 0 : tile % g.nvar;
+        // packed: a second-variant lane holds (acc1, acc2) = (A[0] X_second, A[1] X_first), i.e. that variant's products swapped
+        const float e00 = var ? g.e_alt[1] : (ealt ? g.e_alt[0] : g.e00), e01 = var ? g.e_alt[0] : (ealt ? g.e_alt[1] : g.e01);
+        const float e10 = var ? g.e_alt[3] : (ealt ? g.e_alt[2] : g.e10), e11 = var ? g.e_alt[2] : (ealt ? g.e_alt[3] : g.e11);
         char *D0 = reinterpret_cast<char *>((ealt ? g.dst_alt : g.dst[0]) + bz * g.sC + n0);
+        const unsigned dvar = var ? (unsigned)((g.dst_alt - g.dst[0]) * 4) : 0u;      // second variant's array, as a lane offset
         char *D1 = reinterpret_cast<char *>((g.dst[1] ? g.dst[1] : g.dst[0]) + bz * g.sC + n0);
         const int em0 = m0;
         // row (em0 + rr + 4 h) through a running scalar pointer + the lane's (4 h, column) offset; mirror row
         // Rn - row = (Rn - em0 - 4 - rr) + 4 (1 - h) likewise
         char *Dk0 = D0 + (long)em0 * ldcB, *Dk1 = D1 + (long)em0 * ldcB, *Dm0 = D0 + (long)(g.Rn - em0 - 4) * ldcB;
-        const unsigned lo = (unsigned)(4 * h) * ldc4 + c4, lm = (unsigned)(4 * (1 - h)) * ldc4 + c4;
-        const int next = g.strided ? tile + (int)gridDim.x
+        const unsigned lo = (unsigned)(4 * h) * ldc4 + c4 + dvar, lm = (unsigned)(4 * (1 - h)) * ldc4 + c4 + dvar;
+        const int next = (g.strided || packed) ? tile + (int)gridDim.x
                                    : (((tile % g.nvar) + 1 < g.nvar) ? tile + 1 : tile + 1 + ((int)gridDim.x - 1) * g.nvar);
         const bool more = next < ntile;
         if (more) {
@@ -272,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void dft_rx3_kernel(DftRx3Args g) {
                 }
         }
         if (!more) break;
-        if (MIX && (g.strided || (next % g.nvar) == 0)) RX_MIXTAB();   // every wave finished reading the old table before the last barrier
+        if (MIX && (g.strided || packed || (next % g.nvar) == 0)) RX_MIXTAB();   // every wave finished reading the old table before the last barrier
         __syncthreads();
         RX_BFOLD(0);
         split8(x0, b0h, b0m, b0l);
@@ -312,8 +320,10 @@ int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g) {
     if (g.nvar != 1 && (g.nvar != 2 || g.mode != 0 || !g.dst_alt || !g.A_alt[0] || !g.A_alt[1])) return (int)hipErrorInvalidValue;
     const long ntile = (long)(g.N / 128) * (g.MP / 128) * g.batch;
     DftRx3Args a = g;
-    a.strided = (ntile < slots) ? 1 : 0;
-    const long units = a.strided ? ntile * g.nvar : ntile;
+    const long dalt = (g.nvar == 2 && g.dst_alt) ? (long)(g.dst_alt - g.dst[0]) * 4 : -1;
+    a.packed = (g.packed && g.nvar == 2 && kind == 0 && g.mode == 0 && g.N % 64 == 0 && dalt >= 0 && dalt < 2147483648L) ? 1 : 0;
+    a.strided = (!a.packed && ntile < slots) ? 1 : 0;
+    const long units = a.packed ? (long)(g.N / 64) * (g.MP / 128) * g.batch : (a.strided ? ntile * g.nvar : ntile);
     dim3 grid((unsigned)(units < slots ? units : slots));
     static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
     if (g.mhat) {

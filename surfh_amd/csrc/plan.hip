@@ -120,6 +120,7 @@ struct surfh_plan {
     float *Cma = nullptr, *Sma = nullptr, *Gc = nullptr, *Gs = nullptr, *Cf = nullptr, *Sf = nullptr;
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
     int n_cu = 256;
+    int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
     bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
@@ -622,7 +623,7 @@ int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
         h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
         h.A[0] = p->Cma3; h.A[1] = p->Sma3; h.fold[0] = 1.f; h.fold[1] = -1.f; h.dst[0] = dst;
         h.e00 = 1.f; h.e01 = 1.f; h.e10 = 1.f; h.e11 = -1.f;
-        h.nvar = 2;
+        h.nvar = 2; h.packed = p->rx3_packed;
         h.A_alt[0] = p->Sma3; h.A_alt[1] = p->Cma3; h.fold_alt[0] = -1.f; h.fold_alt[1] = 1.f; h.dst_alt = dst + p->PL * LP;
         h.e_alt[0] = -1.f; h.e_alt[1] = 1.f; h.e_alt[2] = 1.f; h.e_alt[3] = 1.f;
         Prof pr(p, "dft_rx3_cols_fwd");
@@ -642,7 +643,7 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
         g.MP = p->MPa; g.KP = p->KPa; g.N = (int)(hb * LP);
         g.A[0] = p->Cma3; g.A[1] = p->Sma3; g.fold[0] = 1.f; g.fold[1] = -1.f; g.dst[0] = p->ycol;
         g.e00 = 1.f; g.e01 = -1.f; g.e10 = 1.f; g.e11 = 1.f;
-        g.nvar = 2;
+        g.nvar = 2; g.packed = p->rx3_packed;
         g.A_alt[0] = p->Sma3; g.A_alt[1] = p->Cma3; g.fold_alt[0] = -1.f; g.fold_alt[1] = 1.f;
         g.dst_alt = p->ycol + (long)p->NAP * p->KBP * LP;
         g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = -1.f; g.e_alt[3] = 1.f;
@@ -1056,6 +1057,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         const char *e7 = getenv("SURFH_OVERLAP");
         p->overlap = e7 && e7[0] == '1';
         if (p->overlap && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+        const char *e8 = getenv("SURFH_DFT_PACKED");
+        p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
         const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;

@@ -1,6 +1,7 @@
 // micro-benchmark of the register-direct split-bf16 DFT pass: shapes of config 3's four passes
 #include <hip/hip_runtime.h>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 #include "../../surfh_amd/csrc/dft_rx3.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -31,10 +32,12 @@ int main() {
             name = "cols_fwd(2v)"; g.src[0] = ycol; g.src[1] = ycol + (long)KBP * NAP * LP; g.ldb = LP; g.sB = NAP * LP; g.fold[0] = 1; g.fold[1] = -1; g.Kn = Na;
             g.dst[0] = spec; g.ldc = KBP * LP; g.sC = LP; g.mode = 0; g.Rn = Na; g.rvalid = ha; g.e01 = 1; g.e10 = 1; g.e11 = -1; g.N = (int)LP; g.batch = hb;
             g.nvar = 2; g.A_alt[0] = g.A[1]; g.A_alt[1] = g.A[0]; g.fold_alt[0] = -1; g.fold_alt[1] = 1; g.dst_alt = spec + (long)NAP * KBP * LP;
+            g.packed = getenv("RX3_PACKED") ? 1 : 0;
         } else if (pass == 2) {   // c2c along alpha, unbatched wide N
             name = "cols_inv(2v)"; g.src[0] = spec; g.src[1] = spec + (long)NAP * KBP * LP; g.ldb = KBP * LP; g.fold[0] = 1; g.fold[1] = -1; g.Kn = Na;
             g.dst[0] = ycol; g.ldc = KBP * LP; g.mode = 0; g.Rn = Na; g.rvalid = ha; g.e01 = -1; g.e10 = 1; g.e11 = 1; g.N = (int)(hb * LP);
             g.nvar = 2; g.A_alt[0] = g.A[1]; g.A_alt[1] = g.A[0]; g.fold_alt[0] = -1; g.fold_alt[1] = 1; g.dst_alt = ycol + (long)NAP * KBP * LP;
+            g.packed = getenv("RX3_PACKED") ? 1 : 0;
         } else {                  // c2r along beta batched over alpha
             name = "rows_inv"; g.src[0] = ycol; g.src[1] = ycol + (long)NAP * KBP * LP; g.ldb = LP; g.sB = KBP * LP;
             g.dst[0] = cube; g.ldc = NAP * LP; g.sC = LP; g.mode = 0; g.e01 = -1; g.e10 = 1; g.e11 = 1; g.Rn = Nb; g.rvalid = hb; g.N = (int)LP; g.batch = Na;
