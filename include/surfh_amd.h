@@ -147,6 +147,10 @@ int surfh_cg_step_dev(surfh_plan *plan, float *x_dev, float *r_dev, const float 
                       const float *q_dev, int64_t n, double rr_in, double *rr_out_host);
 /* d = r + beta d */
 int surfh_cg_dir_dev(surfh_plan *plan, float *d_dev, const float *r_dev, int64_t n, double beta);
+/* the two calls above fused (one host synchronisation per CG iteration instead of two):
+ * x += s d, r -= s q with s = rr_in / d.q; *rr_out = r.r; d = r + (*rr_out / rr_in) d        */
+int surfh_cg_iter_dev(surfh_plan *plan, float *x_dev, float *r_dev, float *d_dev, const float *q_dev, int64_t n,
+                      double rr_in, double *rr_out);
 /* r = b - q */
 int surfh_residual_dev(surfh_plan *plan, float *r_dev, const float *b_dev, const float *q_dev, int64_t n);
 

@@ -1357,6 +1357,18 @@ int surfh_cg_dir_dev(surfh_plan *p, float *d, const float *r, int64_t n, double 
     LAUNCH_OK(launch_cg_dir(p->stream, d, r, n, p->dscal + 3, p->dscal + 4));
     return 0;
 }
+// cg_step + cg_dir in one call with one host synchronisation: x += s d, r -= s q, rr' = r.r, d = r + (rr'/rr) d
+int surfh_cg_iter_dev(surfh_plan *p, float *x, float *r, float *d, const float *q, int64_t n, double rr_in, double *rr_out) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    HIP_OK(hipMemcpyAsync(p->dscal + 0, &rr_in, sizeof(double), hipMemcpyHostToDevice, p->stream));
+    LAUNCH_OK(launch_dot(p->stream, d, q, n, p->dscratch, p->dscal + 1));
+    LAUNCH_OK(launch_cg_step(p->stream, x, r, d, q, n, p->dscal + 0, p->dscal + 1, p->dscratch, p->dscal + 2));
+    LAUNCH_OK(launch_cg_dir(p->stream, d, r, n, p->dscal + 2, p->dscal + 0));
+    HIP_OK(hipMemcpyAsync(rr_out, p->dscal + 2, sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));   // also covers the pageable rr_in copy
+    return 0;
+}
 int surfh_residual_dev(surfh_plan *p, float *r, const float *b, const float *q, int64_t n) {
     if (!p) return fail("null plan");
     HIP_OK(hipSetDevice(p->dev));

@@ -350,12 +350,16 @@ class DistributedFusion:
         torch, m = self.torch, self.model
         with self._ctx():
             self.normal(self.d, self.q, self.mu, self.mu_reg)
-            rr_new = m.cg_step_dev(self.x, self.r, self.d, self.q, self.n, self.rr)
-            if refresh and self.it % refresh == 0:
-                self.normal(self.x, self.q, self.mu, self.mu_reg)
-                m.residual_dev(self.r, self.b, self.q, self.n)
-                rr_new = m.dot_dev(self.r, self.r, self.n)
-            m.cg_dir_dev(self.d, self.r, self.n, rr_new / self.rr)
+            fused = getattr(m, "cg_iter_dev", None)
+            if fused is not None and not (refresh and self.it % refresh == 0):
+                rr_new = fused(self.x, self.r, self.d, self.q, self.n, self.rr)     # one host sync per iteration
+            else:
+                rr_new = m.cg_step_dev(self.x, self.r, self.d, self.q, self.n, self.rr)
+                if refresh and self.it % refresh == 0:
+                    self.normal(self.x, self.q, self.mu, self.mu_reg)
+                    m.residual_dev(self.r, self.b, self.q, self.n)
+                    rr_new = m.dot_dev(self.r, self.r, self.n)
+                m.cg_dir_dev(self.d, self.r, self.n, rr_new / self.rr)
         self.rr = rr_new
         self.grad_norm.append(rr_new)
         self.it += 1

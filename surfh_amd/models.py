@@ -175,6 +175,12 @@ class spectroSigRLSCT(LinOp):
                                              C.byref(out)))
         return out.value
 
+    def cg_iter_dev(self, x_t, r_t, d_t, q_t, n: int, rr: float) -> float:
+        """cg_step_dev + cg_dir_dev with one host synchronisation; returns the new r.r."""
+        out = C.c_double()
+        _lib.check(self._L.surfh_cg_iter_dev(self._plan, _ptr(x_t), _ptr(r_t), _ptr(d_t), _ptr(q_t), int(n), float(rr), C.byref(out)))
+        return out.value
+
     def cg_dir_dev(self, d_t, r_t, n: int, beta: float):
         _lib.check(self._L.surfh_cg_dir_dev(self._plan, _ptr(d_t), _ptr(r_t), int(n), float(beta)))
 

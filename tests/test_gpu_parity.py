@@ -282,6 +282,31 @@ def test_device_pointer_api_and_profile(c1):
     assert abs(m.dot_dev(x, x, n) - float(np.sum(cfg["maps"].astype(np.float32).astype(np.float64) ** 2))) < 1e-6 * n
 
 
+def test_distributed_loop_matches_single_call_cg(c1):
+    """DistributedFusion on one rank (the benchmark's loop: device vectors, fused step+direction call with one host
+    synchronisation per iteration) gives the same iterates with and without the fused call (bit for bit) and agrees with surfh_cg."""
+    import torch
+    from surfh_amd.fusion import DistributedFusion
+    cfg, om, m = c1
+    y = om.forward(cfg["maps"])
+    x_ref, gn_ref, _ = m.cg(y, mu=1.0, mu_reg=5e3, x0=None, max_iter=8)
+    from helpers import make_ifu, make_pointings
+    prob = dict(ifus=[make_ifu(s) for s in cfg["specs"]], pointings=make_pointings(cfg), alpha_axis=cfg["alpha_axis"],
+                beta_axis=cfg["beta_axis"], wavel=cfg["wavel"], step_deg=cfg["step_deg"], sotf=cfg["sotf"],
+                templates=cfg["templates"])
+    out = {}
+    for fused in (True, False):
+        fus = DistributedFusion(prob, rank=0, world=1, device=0)
+        if not fused:
+            fus.model.cg_iter_dev = None                    # instance attribute shadows the method: two-call path
+        yt = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32), device="cuda:0")
+        res = fus.lcg(yt, mu=1.0, mu_reg=5e3, max_iter=8)
+        out[fused] = (np.asarray(res.grad_norm), res.x.reshape(x_ref.shape))
+        fus.model.close()
+    assert np.array_equal(out[True][0], out[False][0]) and np.array_equal(out[True][1], out[False][1])   # same arithmetic
+    assert float(np.max(np.abs(out[True][0] - gn_ref) / gn_ref)) < 1e-5 and rel(out[True][1], x_ref) < 1e-5
+
+
 def test_quad_criterion_mirror(c1):
     """QuadCriterion_MRS.run_method('lcg') / get_crit_val (surfh/Simulation/fusion_CT.py:66-265) on the device CG."""
     from surfh_amd.fusion import QuadCriterion_MRS
