@@ -100,3 +100,59 @@ def test_other_image_sizes(N, Lc):
         assert ef < 1e-5 and ea < 1e-5 and abs(l - r) / abs(r) < 1e-6
     finally:
         m.close()
+
+
+def test_config5_deconvolution_path_full_size():
+    """BASELINE.json configs[4]: 512x512x2048, band 1C geometry without rotation
+    (scripts/deconvolution_mrs_noRotation.py:100-118), the 2-D operator batched over wavelength and the Fourier-domain
+    spectral-mix model.  No oracle finishes at this size: size-independent properties (dot test, fwadj = adjoint o forward)
+    on the whole arrays, parity against the float64 oracle on three of the 2048 planes."""
+    from surfh_amd import instru
+    from surfh_amd.mixing import Model_WCT
+    from surfh_amd.spectro_blind_rectangle import MRSBlurred
+    from helpers import make_ifu
+    N, Lc, T = 512, 2048, 4
+    t0 = time.time()
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    wav = np.linspace(6.53, 7.65, Lc)
+    psfs = orc.gaussian_psf(wav, problems.STEP)
+    spec = orc.ChannelSpec(3.2 / 3600, 3.7 / 3600, (0.0, 0.0), 0.0, 0.196, 21, 3355.0, np.linspace(6.6, 7.6, 10), "1C")
+    s = problems.STEP_DEG
+    pts = [(0.0, 0.0), (2 * s, -3 * s), (-4 * s, 1 * s), (3 * s, 5 * s)]
+    rng = np.random.default_rng(5)
+
+    # ---- Model_WCT: maps[4] <-> cube[2048]
+    tpl = orc.synthetic_templates(Lc)[:T] / 1e3
+    pce = np.ones(Lc)
+    m = Model_WCT(psfs, tpl, (N, N), pce)
+    x = rng.random((T, N, N)).astype(np.float32)
+    cube = m.forward(x)
+    assert cube.shape == (Lc, N, N)
+    u = rng.random((Lc, N, N), dtype=np.float32)
+    au = m.adjoint(u)
+    l = float(np.vdot(au.astype(np.float64), x.astype(np.float64))); r = float(np.vdot(u.astype(np.float64), cube))
+    gap = abs(l - r) / abs(r)
+    e_fwadj = rel(m.fwadj(x), m.adjoint(cube))
+    sel = [0, 1000, 2047]
+    wo = orc.WCTOracle(psfs[sel], tpl[:, sel], (N, N), pce[sel])
+    e_par = rel(cube[sel], wo.forward(x))
+    print(f"config5 Model_WCT: dot gap {gap:.2e}, fwadj vs adjoint(forward) {e_fwadj:.2e}, forward parity on planes {sel}: {e_par:.2e} "
+          f"({time.time() - t0:.0f}s)", flush=True)
+    assert gap < 1e-6 and e_fwadj < 1e-5 and e_par < 1e-5
+    m.close()
+    del cube, au
+
+    # ---- MRSBlurred batched over the 2048 planes
+    sotf = orc.ir2fr(psfs, (N, N))
+    mb = MRSBlurred(sotf, ax, ax, make_ifu(spec), s, instru.CoordList([instru.Coord(a, b) for a, b in pts]))
+    y = mb.forward(u)
+    assert y.shape[0] == Lc
+    v = rng.random(y.shape, dtype=np.float32)
+    av = mb.adjoint(v)
+    l = float(np.vdot(av, u.astype(np.float64))); r = float(np.vdot(v.astype(np.float64), y))
+    gap = abs(l - r) / abs(r)
+    bo = orc.BlurredOracle(sotf[sel], ax, ax, spec, s, pts)
+    e_par = rel(y[sel], bo.forward(u[sel].astype(np.float64)))
+    print(f"config5 MRSBlurred x{Lc}: dot gap {gap:.2e}, forward parity on planes {sel}: {e_par:.2e} ({time.time() - t0:.0f}s)", flush=True)
+    assert gap < 1e-6 and e_par < 1e-5
+    mb.close()
