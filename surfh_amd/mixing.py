@@ -185,3 +185,46 @@ class MixingST(LinOp):
     def mapsToCube(self, maps):
         """Unmasked LMM (mixing.py:330-334)."""
         return np.sum(np.expand_dims(np.asarray(maps), 1) * self.templates[..., np.newaxis, np.newaxis], axis=0)
+
+
+class ShardedWCT:
+    """``Model_WCT`` sharded over wavelength: rank r owns a contiguous slice of the planes.
+    ``forward`` returns the rank's slice of the cube (planes are independent, no exchange); ``adjoint`` and ``fwadj`` sum
+    over wavelength, so their per-rank partial maps are all-reduced through ``torch.distributed`` -- one collective of
+    [T, Na, Nb] per application, the same exchange as the fusion CG.  ``model_factory(psfs, specs, shape, pce)`` replaces
+    the HIP operator (CPU rehearsal with the checker)."""
+
+    def __init__(self, psfs_monoch, L_specs, shape_target, L_pce, rank: int = 0, world: int = 1, *, device: int = 0,
+                 model_factory=None):
+        L = np.asarray(L_specs).shape[1]
+        self.rank, self.world = rank, world
+        self.lo, self.hi = (L * rank) // world, (L * (rank + 1)) // world
+        if self.hi <= self.lo:
+            raise ValueError(f"rank {rank} of {world} owns no plane of {L}")
+        sl = slice(self.lo, self.hi)
+        mk = model_factory or (lambda a, b, c, d: Model_WCT(a, b, c, d, device=device))
+        self.model = mk(np.asarray(psfs_monoch)[sl], np.asarray(L_specs)[:, sl], shape_target, np.asarray(L_pce)[sl])
+        self.ishape = tuple(self.model.ishape)
+        self.oshape = (self.hi - self.lo,) + tuple(shape_target)
+
+    def _allreduce(self, a):
+        if self.world == 1:
+            return a
+        import torch
+        import torch.distributed as dist
+        t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64))
+        dist.all_reduce(t)
+        return t.numpy()
+
+    def forward(self, x):
+        return self.model.forward(x)                 # this rank's planes [lo, hi)
+
+    def adjoint(self, y_local):
+        return self._allreduce(self.model.adjoint(y_local))
+
+    def fwadj(self, x):
+        return self._allreduce(self.model.fwadj(x))
+
+    def close(self):
+        if hasattr(self.model, "close"):
+            self.model.close()
