@@ -137,6 +137,13 @@ int surfh_maps_to_cube(surfh_plan *plan, const double *templates, int32_t n_temp
 int surfh_cube_to_maps(surfh_plan *plan, const double *templates, int32_t n_templates, int32_t n_lambda,
                        const float *cube, float *maps);
 
+/* The same solver for the plane-wise model (n_templates = 0: x is the cube [Lc][Na][Nb]): every plane is an independent
+ * 2-D problem  mu |y_l - A_l x_l|^2 + mu_reg (|Dr x_l|^2 + |Dc x_l|^2)  with its own CG scalars -- the reference's 2-D
+ * deconvolution (surfh/Simulation/criterion_2D.py:60-250, scripts/deconvolution_mrs_noRotation.py) batched over
+ * wavelength.  grad_norm receives r_l.r_l as [max_iter+1][Lc]; the loop stops when every plane is below the tolerance. */
+int surfh_cg_planes(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,
+                    double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
+
 /* CG building blocks on device vectors, for the multi-GPU driver (one plan per rank,
  * RCCL all-reduce of `q` between surfh_normal_dev and surfh_cg_step_dev).            */
 int surfh_normal_dev(surfh_plan *plan, const float *d_dev, float *q_dev, double mu);          /* q  = mu A^T A d   */

@@ -63,6 +63,11 @@ int launch_cg_xupdate(hipStream_t s, float *x, const float *d, long n, const dou
 int launch_cg_dir(hipStream_t s, float *d, const float *r, long n, const double *rr_new, const double *rr_old);
 // r = b - q
 int launch_residual(hipStream_t s, float *r, const float *b, const float *q, long n);
+// CG on independent planes ([nplanes][npix] arrays, per-plane scalars in double arrays of nplanes)
+int launch_dot_planes(hipStream_t s, const float *a, const float *b, int nplanes, long npix, double *out);
+int launch_cg_step_planes(hipStream_t s, float *x, float *r, const float *d, const float *q, int nplanes, long npix, const double *rr,
+                          const double *dq, double *rrn, int update_r);
+int launch_cg_dir_planes(hipStream_t s, float *d, const float *r, int nplanes, long npix, const double *rrn, double *rr);
 // (hth + diag(mu reg)) z = in per frequency bin (reg < 0 marks padding bins); *flag |= 1 on a non-positive pivot
 int launch_wct_solve(hipStream_t s, const float *hth, const float *reg, const double *mu, const float *in, float *out, int T,
                      long PL, int *flag);

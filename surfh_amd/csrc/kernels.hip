@@ -453,6 +453,51 @@ __global__ __launch_bounds__(TPB) void residual_kernel(float *__restrict__ r, co
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) r[i] = b[i] - q[i];
 }
 
+// ---- CG on a batch of independent planes (the 2-D deconvolution path, one problem per wavelength): every plane has
+// its own step and direction scalars.  One workgroup per plane; fp64 sums; a plane whose residual is already zero
+// (no data, or converged exactly) keeps still.
+__global__ __launch_bounds__(TPB) void dot_planes_kernel(const float *__restrict__ a, const float *__restrict__ b, long npix,
+                                                         double *__restrict__ out) {
+    const long off = (long)blockIdx.x * npix;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < npix; i += TPB) s += (double)a[off + i] * (double)b[off + i];
+    s = block_sum(s);
+    if (threadIdx.x == 0) out[blockIdx.x] = s;
+}
+
+// x += s d ; (update_r) r -= s q, rr' = r.r      with s = rr / dq of this plane
+__global__ __launch_bounds__(TPB) void cg_step_planes_kernel(float *__restrict__ x, float *__restrict__ r, const float *__restrict__ d,
+                                                             const float *__restrict__ q, long npix, const double *__restrict__ rr,
+                                                             const double *__restrict__ dq, double *__restrict__ rrn, int update_r) {
+    const long off = (long)blockIdx.x * npix;
+    const double den = dq[blockIdx.x];
+    const float step = den != 0.0 ? (float)(rr[blockIdx.x] / den) : 0.f;
+    double s = 0.0;
+    for (long i = threadIdx.x; i < npix; i += TPB) {
+        x[off + i] += step * d[off + i];
+        if (update_r) {
+            const float rn = r[off + i] - step * q[off + i];
+            r[off + i] = rn;
+            s += (double)rn * (double)rn;
+        }
+    }
+    if (update_r) {
+        s = block_sum(s);
+        if (threadIdx.x == 0) rrn[blockIdx.x] = s;
+    }
+}
+
+// d = r + (rr' / rr) d per plane, then rr <- rr'
+__global__ __launch_bounds__(TPB) void cg_dir_planes_kernel(float *__restrict__ d, const float *__restrict__ r, long npix,
+                                                            const double *__restrict__ rrn, double *__restrict__ rr) {
+    const long off = (long)blockIdx.x * npix;
+    const double old = rr[blockIdx.x];
+    const float beta = old != 0.0 ? (float)(rrn[blockIdx.x] / old) : 0.f;
+    for (long i = threadIdx.x; i < npix; i += TPB) d[off + i] = r[off + i] + beta * d[off + i];
+    __syncthreads();
+    if (threadIdx.x == 0) rr[blockIdx.x] = rrn[blockIdx.x];
+}
+
 inline int nblocks(long n, int cap = 2048) {
     long b = (n + TPB - 1) / TPB;
     if (b < 1) b = 1;
@@ -634,5 +679,21 @@ int launch_lmm_cube2maps(hipStream_t s, const float *cube, const float *tpl, flo
 int launch_wct_solve(hipStream_t s, const float *hth, const float *reg, const double *mu, const float *in, float *out, int T,
                      long PL, int *flag) {
     hipLaunchKernelGGL(wct_solve_kernel, dim3((unsigned)((PL + TPB - 1) / TPB)), dim3(TPB), 0, s, hth, reg, mu, in, out, T, PL, flag);
+    return (int)hipGetLastError();
+}
+
+int launch_dot_planes(hipStream_t s, const float *a, const float *b, int nplanes, long npix, double *out) {
+    hipLaunchKernelGGL(dot_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, a, b, npix, out);
+    return (int)hipGetLastError();
+}
+
+int launch_cg_step_planes(hipStream_t s, float *x, float *r, const float *d, const float *q, int nplanes, long npix, const double *rr,
+                          const double *dq, double *rrn, int update_r) {
+    hipLaunchKernelGGL(cg_step_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, x, r, d, q, npix, rr, dq, rrn, update_r);
+    return (int)hipGetLastError();
+}
+
+int launch_cg_dir_planes(hipStream_t s, float *d, const float *r, int nplanes, long npix, const double *rrn, double *rr) {
+    hipLaunchKernelGGL(cg_dir_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, d, r, npix, rrn, rr);
     return (int)hipGetLastError();
 }

@@ -1447,6 +1447,68 @@ int surfh_cg(surfh_plan *p, const float *y, double mu, double mu_reg, const floa
     return surfh_cg_cb(p, y, mu, mu_reg, x0, max_iter, tol, refresh, x, grad_norm, nit, nullptr, nullptr);
 }
 
+// ---- CG on independent planes: the 2-D deconvolution path (criterion_2D.py:60-250 per image, batched over wavelength)
+int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+                    int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+    if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
+    if (p->T != 0) return fail("surfh_cg_planes is the solver of the plane-wise (no template) model; use surfh_cg with templates");
+    if (p->ch.empty()) return fail("plan has no channel");
+    HIP_OK(hipSetDevice(p->dev));
+    if (ensure_cg(p)) return 1;
+    hipStream_t s = p->stream;
+    const int L = p->Lc;
+    const long npix = (long)p->Na * p->Nb, n = p->isize;
+    double *sc = nullptr;              // [3][L]: rr, dq, rr'
+    HIP_OK(hipMalloc((void **)&sc, (size_t)3 * L * sizeof(double)));
+    double *rr = sc, *dq = sc + L, *rrn = sc + 2 * L;
+    auto done = [&](int rc) { hipFree(sc); return rc; };
+    auto Q = [&](const float *v, float *out) -> int {
+        if (normal_dev(p, v, out, mu)) return 1;
+        if (mu_reg != 0.0) LAUNCH_OK(launch_prior_add(s, v, out, L, p->Na, p->Nb, (float)mu_reg));
+        return 0;
+    };
+    if (hipMemcpyAsync(p->io_y, y, p->osize * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail("copy failed"));
+    if (adjoint_dev(p, p->io_y, p->cg_b, false)) return done(1);
+    int rc = 0;
+    if (mu != 1.0) rc = launch_scale(s, p->cg_b, n, (float)mu);
+    if (!rc) rc = x0 ? (int)hipMemcpyAsync(p->cg_x, x0, n * sizeof(float), hipMemcpyHostToDevice, s) : launch_fill_zero(s, p->cg_x, n);
+    if (rc) return done(fail("cg setup failed"));
+    if (Q(p->cg_x, p->cg_q)) return done(1);
+    rc = launch_residual(s, p->cg_r, p->cg_b, p->cg_q, n);
+    if (!rc) rc = (int)hipMemcpyAsync(p->cg_d, p->cg_r, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+    if (!rc) rc = launch_dot_planes(s, p->cg_r, p->cg_r, L, npix, rr);
+    if (!rc) rc = (int)hipMemcpyAsync(grad_norm, rr, L * sizeof(double), hipMemcpyDeviceToHost, s);
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    if (rc) return done(fail("cg setup failed: %s", hipGetErrorString((hipError_t)rc)));
+    *nit = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        if (Q(p->cg_d, p->cg_q)) return done(1);
+        rc = launch_dot_planes(s, p->cg_d, p->cg_q, L, npix, dq);
+        if (!rc && refresh > 0 && it % refresh == 0) {     // residual recomputed from scratch (qmm.lcg restated, see surfh_cg)
+            rc = launch_cg_step_planes(s, p->cg_x, p->cg_r, p->cg_d, p->cg_q, L, npix, rr, dq, rrn, 0);
+            if (rc) return done(fail("launch failed"));
+            if (Q(p->cg_x, p->cg_q)) return done(1);
+            rc = launch_residual(s, p->cg_r, p->cg_b, p->cg_q, n);
+            if (!rc) rc = launch_dot_planes(s, p->cg_r, p->cg_r, L, npix, rrn);
+        } else if (!rc) {
+            rc = launch_cg_step_planes(s, p->cg_x, p->cg_r, p->cg_d, p->cg_q, L, npix, rr, dq, rrn, 1);
+        }
+        if (!rc) rc = launch_cg_dir_planes(s, p->cg_d, p->cg_r, L, npix, rrn, rr);
+        double *gn = grad_norm + (size_t)(it + 1) * L;
+        if (!rc) rc = (int)hipMemcpyAsync(gn, rr, L * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (!rc) rc = (int)hipStreamSynchronize(s);
+        if (rc) return done(fail("cg iteration failed: %s", hipGetErrorString((hipError_t)rc)));
+        *nit = it + 1;
+        double worst = 0.0;
+        for (int l = 0; l < L; ++l) worst = std::max(worst, gn[l]);
+        if (std::sqrt(worst) < (double)npix * tol) break;
+    }
+    rc = (int)hipMemcpyAsync(x, p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    if (rc) return done(fail("copy failed"));
+    return done(0);
+}
+
 // ---- drivers' LMM helpers on the device (spectroModel.py:187-198) -----------------------------
 static int lmm_host(surfh_plan *p, const double *templates, int32_t T, int32_t L, const float *in, float *out, bool to_cube) {
     if (!p || !templates || !in || !out) return fail("null argument");

@@ -170,3 +170,66 @@ class MRSBlurred(LinOp):
 
     def adjoint(self, data):
         return self._call(self._L.surfh_adjoint, data, self.osize, self.ishape)
+
+    # ---- solver: regularised least squares by CG, one independent 2-D problem per plane -------------------
+    def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+        """Device-resident linear CG on  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2)  (criterion_2D.py:60-250 with
+        `qmm.lcg` restated).  Batched model: every plane is its own problem with its own step sizes; returns
+        ``(x, grad_norm, nit)`` with ``grad_norm`` of shape ``[nit+1]`` (single image) or ``[nit+1, n_planes]``."""
+        y = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
+        if y.size != self.osize:
+            raise ValueError("data size mismatch")
+        x0a = None if x0 is None else np.ascontiguousarray(np.asarray(x0, dtype=np.float32).reshape(-1))
+        if x0a is not None and x0a.size != self.isize:
+            raise ValueError("x0 size mismatch")
+        x = np.empty(self.isize, dtype=np.float32)
+        gn = np.zeros((max_iter + 1, self.n_planes), dtype=np.float64)
+        nit = C.c_int32()
+        _lib.check(self._L.surfh_cg_planes(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
+                                           _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol), int(refresh),
+                                           _lib.fptr(x), _lib.dptr(gn), C.byref(nit)))
+        gn = gn[: nit.value + 1]
+        return x.astype(np.float64).reshape(self.ishape), (gn if self.batched else gn[:, 0]).copy(), nit.value
+
+
+class QuadCriterion_MRS_2D:
+    """The reference's 2-D criterion (surfh/Simulation/criterion_2D.py:66-250): same constructor, ``run_method('lcg')``
+    and ``get_crit_val``, on ``MRSBlurred`` (one image, or a stack of independent images solved together)."""
+
+    def __init__(self, mu_spectro, y_spectro, model_spectro, mu_reg, printing=False, gradient="separated"):
+        assert isinstance(mu_reg, (float, int, list, np.ndarray))
+        if gradient != "separated":
+            raise NotImplementedError("only the separated first-difference priors (NpDiff_r / NpDiff_c) are built")
+        self.mu_spectro, self.y_spectro, self.model_spectro, self.mu_reg = mu_spectro, y_spectro, model_spectro, mu_reg
+        self.shape_of_output = tuple(model_spectro.ishape)
+        self.printing, self.gradient, self.it = printing, gradient, 1
+        self.L_crit_val = []
+
+    def run_method(self, method="lcg", maximum_iterations=10, tolerance=1e-12, calc_crit=False, perf_crit=None, value_init=0.5):
+        assert isinstance(self.mu_reg, (int, float))             # criterion_2D.py:115
+        if method != "lcg":
+            raise NotImplementedError("only method='lcg' is built (mmmg is out of the hot-path scope)")
+        if calc_crit or perf_crit is not None:
+            raise NotImplementedError("per-iteration callbacks are built for the fusion criterion (QuadCriterion_MRS) only")
+        init = np.ones(self.shape_of_output) * value_init if isinstance(value_init, (int, float)) else value_init
+        assert tuple(np.shape(init)) == self.shape_of_output
+        import time
+        from .fusion import OptimizeResult
+        t0 = time.time()
+        x, gn, nit = self.model_spectro.cg(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
+                                           max_iter=maximum_iterations, tol=tolerance)
+        last = np.max(np.atleast_1d(gn[-1]))
+        res = OptimizeResult(x=x.ravel(), grad_norm=list(gn), nit=nit,
+                             success=bool(np.sqrt(last) < np.prod(self.shape_of_output[-2:]) * tolerance), time=time.time() - t0)
+        if self.printing:
+            print(f"Total time needed for {method} :", round(res.time, 3))
+        return res
+
+    def get_crit_val(self, x_hat):
+        """(mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2)) / 2   (criterion_2D.py:252-275), summed over the planes."""
+        x_hat = np.asarray(x_hat).reshape(self.shape_of_output)
+        data = self.mu_spectro * np.sum((np.asarray(self.y_spectro).reshape(self.model_spectro.oshape)
+                                         - self.model_spectro.forward(x_hat)) ** 2)
+        dr = np.roll(x_hat, 1, axis=-2) - x_hat
+        dc = np.roll(x_hat, 1, axis=-1) - x_hat
+        return (data + self.mu_reg * np.sum(dr ** 2 + dc ** 2)) / 2

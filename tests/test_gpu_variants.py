@@ -191,3 +191,58 @@ def test_masked_mixing_model_vs_reference():
         MixingST(tpl, np.arange(na, dtype=float), np.arange(nb, dtype=float), np.arange(L, dtype=float), sel, np.array([[L, 0, 0]]))
     for mm in (m, m2, m3):
         mm.close()
+
+
+class _PlaneOp:
+    """One plane of the 2-D oracle presented as a [1, N, N] operator (the checker's lcg and priors act on [T, N, N])."""
+    def __init__(self, bo):
+        self.bo = bo
+    def forward(self, x):
+        return self.bo.forward(x[0])
+    def adjoint(self, y):
+        return self.bo.adjoint(y)[None]
+
+
+def test_plane_wise_cg_2d_deconvolution():
+    """SURVEY.md 8f-3 (solver part): regularised least squares by CG on the 2-D model, one independent problem per plane
+    (criterion_2D.py:66-250 with qmm.lcg restated -- parity unpinned like the fusion solver, checked against the float64
+    restatement plane by plane)."""
+    from surfh_amd import instru
+    from surfh_amd.spectro_blind_rectangle import MRSBlurred, QuadCriterion_MRS_2D
+    L = 5
+    N, bo, m = blurred_case(L=L)
+    rng = np.random.default_rng(4)
+    truth = rng.random((L, N, N))
+    y = bo.forward(truth)
+    y[3] = 0.0                                                # a plane without data must stay at rest (no 0/0)
+    mu, mur, nit = 1.0, 0.05, 10
+    x, gn, n = m.cg(y, mu=mu, mu_reg=mur, x0=None, max_iter=nit)
+    assert n == nit and gn.shape == (nit + 1, L) and x.shape == (L, N, N)
+    assert not x[3].any() and not gn[:, 3].any() and np.isfinite(x).all()
+    # per-plane oracle: the same plane solved alone in float64
+    wav = np.linspace(7.0, 8.2, L)
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    s_ = problems.STEP_DEG
+    pts = [(0.0, 0.0), (2 * s_, -3 * s_), (-4 * s_, 1 * s_)]
+    spec = orc.ChannelSpec(1.0 / 3600, 1.2 / 3600, (0.0, 0.0), 0.0, 0.196, 12, 3000.0, np.linspace(7, 8, 10), "R")
+    for l in (0, 2, 4):
+        sotf_l = orc.ir2fr(orc.gaussian_psf(wav[l:l + 1], problems.STEP), (N, N))[0]
+        op = _PlaneOp(orc.BlurredOracle(sotf_l, ax, ax, spec, s_, pts))
+        ref = orc.lcg(op, y[l], mu, mur, np.zeros((1, N, N)), tol=1e-12, max_iter=nit)
+        gr = np.array(ref["grad_norm"])
+        assert rel(x[l], ref["x"][0]) < 5e-3, l
+        assert float(np.max(np.abs(gn[:5, l] - gr[:5]) / gr[:5])) < 1e-2 and gn[-1, l] < 1e-2 * gn[0, l]
+    # the single-image model solves its plane to the same iterate
+    sotf2 = orc.ir2fr(orc.gaussian_psf(wav[2:3], problems.STEP), (N, N))[0]
+    m1 = MRSBlurred(sotf2, ax, ax, make_ifu(spec), s_, instru.CoordList([instru.Coord(a, b) for a, b in pts]))
+    x1, gn1, _ = m1.cg(y[2], mu=mu, mu_reg=mur, max_iter=nit)
+    assert x1.shape == (N, N) and gn1.shape == (nit + 1,) and rel(x1, x[2]) < 1e-4 and np.allclose(gn1, gn[:, 2], rtol=1e-3)
+    # the criterion mirror
+    crit = QuadCriterion_MRS_2D(mu, y[2], m1, mur)
+    res = crit.run_method("lcg", maximum_iterations=nit, value_init=0.0)
+    assert res.nit == nit and rel(res.x.reshape(N, N), x1) < 1e-6
+    assert crit.get_crit_val(res.x) < crit.get_crit_val(np.zeros((N, N)))
+    with pytest.raises(NotImplementedError):
+        crit.run_method("mmmg")
+    m.close()
+    m1.close()
