@@ -59,6 +59,12 @@ typedef struct {
     const double *gt_y0;               /* [P][Na*Nb]                                                */
     const double *gt_y1;               /* [P][Na*Nb]                                                */
     const uint8_t *gt_inside;          /* [P][Na*Nb] 1 if the global pixel falls inside the local grid */
+    /* alpha window summed into one detector sample: local rows alpha0 + a*srf + box_shift + [0, box_len) (circular).
+       box_len = 0 means srf with shift 0, the operator's box sum (`_otf_sr * decalf`, spectroModelChannel.py:81-83,
+       104-108).  The real-data projections use other windows: plain decimation (box_len 1,
+       realData_cubeToSlice :303-309) and the box kernel without its re-centring shift (box_shift = -int((srf-1)/2),
+       realData_sliceToCube :331-332).                                                             */
+    int32_t box_len, box_shift;
 } surfh_channel_desc;
 
 typedef struct {
@@ -66,7 +72,8 @@ typedef struct {
     int32_t n_lambda;                  /* cube planes Lc                                            */
     int32_t n_templates;               /* T; 0 => no LMM (input is the cube itself)                 */
     const double *templates;           /* [T][Lc] or NULL                                           */
-    const double *sotf;                /* [Lc][n_alpha][n_beta/2+1] complex128 interleaved (re,im)  */
+    const double *sotf;                /* [Lc][n_alpha][n_beta/2+1] complex128 interleaved (re,im);
+                                          NULL (only with n_templates = 0): no spatial blur, H = 1  */
     int32_t n_channels;
     const surfh_channel_desc *channels;
     int32_t device;                    /* HIP device ordinal                                        */
@@ -128,6 +135,17 @@ typedef int (*surfh_cg_callback)(void *user, int32_t it, const double *grad_norm
 int surfh_cg_cb(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0,
                 int32_t max_iter, double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit,
                 surfh_cg_callback callback, void *user);
+/* 3MG, the reference's other solver choice (`method != 'lcg'` -> qmm.mmmg, fusion_CT.py:194-198; algorithms.py:69,106),
+ * for the same quadratic criterion: every iteration minimises it exactly over span{-gradient, previous move}
+ * (the quadratic majorant of a quadratic objective is the objective).  The 2x2 subspace system is solved in a basis
+ * [d, move] with d Q-orthogonal to the previous move and the operator applied to d -- the same iterates as qmm's
+ * [-gradient, move] form in exact arithmetic, but as accurate as CG in fp32 (see plan.hip).  One normal-operator
+ * application per iteration; the gradient is carried by linearity and recomputed every `refresh` iterations.
+ * grad_norm receives |gradient| of x0 and of every iterate (nit+1 doubles, capacity max_iter+1); stops when it falls
+ * below size*tol.  callback as surfh_cg_cb. */
+int surfh_mmmg(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0,
+               int32_t max_iter, double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit,
+               surfh_cg_callback callback, void *user);
 
 /* ---- linear mixing model on the device: the drivers' mapsToCube / cubeTomaps
  * (spectroModel.py:187-198, jax_utils.py:10-26).  templates [T][Lc] float64 as in surfh_config,

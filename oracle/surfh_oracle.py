@@ -130,8 +130,9 @@ def global2local(ga, gb, angle, origin):
     return c[0].reshape((na, nb)), c[1].reshape((na, nb))
 
 
-def spectral_psf(grating_resolution, out_axis, beta, wavelength, scale, n_margin=15):
-    """SpectralBlur.psfs, type='mrs' (instru.py:499-572).
+def spectral_psf(grating_resolution, out_axis, beta, wavelength, scale, n_margin=15, kind="mrs"):
+    """SpectralBlur.psfs (instru.py:499-572); kind='dirac' (:564-570) keeps a 1 at the peak of every (lambda', beta)
+    response on the margin-extended axis -- the nearest-wavelength selector of Channel.sliceToCube.
 
     Returns W[lambda', lambda, beta]; normalised over the margin-extended input
     axis and then cropped (row sums are < 1 near the ends of the axis).
@@ -152,6 +153,8 @@ def spectral_psf(grating_resolution, out_axis, beta, wavelength, scale, n_margin
     out = (np.pi * grating_len / w_norm
            * np.sinc(np.pi * grating_len * ((out_axis - scale * beta) / w_norm - 1)) ** 2)
     out /= np.sum(out, axis=1, keepdims=True)
+    if kind == "dirac":
+        out = (out == np.max(out, axis=1, keepdims=True)).astype(np.float64)
     return out[:, n_margin - 1: -n_margin + 1, :]
 
 
@@ -232,6 +235,7 @@ class ChannelTables:
     nn_idx: List[np.ndarray] = field(default_factory=list)     # per pointing: flat C-order cube index [na*nb]
     nn_idx_t: List[np.ndarray] = field(default_factory=list)   # per pointing: flat local index per cube pixel [Na*Nb]
     gridding: str = "bilinear"
+    wpsf_dirac: np.ndarray = None                    # [Ldet, Lin, nbeta], one-hot (spectroModelChannel.py:92-95,145-155)
 
 
 def _slit_local_fov(spec: ChannelSpec, s: int):
@@ -328,6 +332,9 @@ def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_deg
     wpsf = spectral_psf(spec.grating_resolution, spec.wavel_axis,
                         beta_in_slit - np.mean(beta_in_slit), wavel_axis[ws[0]:ws[1]],
                         scale=(spec.wavel_axis[1] - spec.wavel_axis[0]) / spec.det_pix_size)
+    wpsf_dirac = spectral_psf(spec.grating_resolution, spec.wavel_axis,
+                              beta_in_slit - np.mean(beta_in_slit), wavel_axis[ws[0]:ws[1]],
+                              scale=(spec.wavel_axis[1] - spec.wavel_axis[0]) / spec.det_pix_size, kind="dirac")
     if lam_slice is not None:      # one of n contiguous parts of the window (the parts' outputs add up)
         lin = ws[1] - ws[0]
         if len(lam_slice) == 3:        # ("planes", a, b)
@@ -336,13 +343,14 @@ def build_channel(spec: ChannelSpec, alpha_axis, beta_axis, wavel_axis, step_deg
             i, n = lam_slice
             a, b = (lin * i) // n, (lin * (i + 1)) // n
         wpsf = wpsf[:, a:b, :]
+        wpsf_dirac = wpsf_dirac[:, a:b, :]
         ws = (ws[0] + a, ws[0] + b)
 
     tab = ChannelTables(spec=spec, srf=srf, origin_pix=origin_pix, pointings=pts, wslice=ws,
                         local_alpha_axis=la, local_beta_axis=lb,
                         npix_slit_alpha_width=npix_a, npix_slit_beta_width=npix_b,
                         n_alpha_out=n_alpha_out, slit_slices=slices, slit_weights=weights, wpsf=wpsf,
-                        oshape=(len(pts), spec.n_slit, len(spec.wavel_axis), n_alpha_out))
+                        oshape=(len(pts), spec.n_slit, len(spec.wavel_axis), n_alpha_out), wpsf_dirac=wpsf_dirac)
     if with_grid:
         for p in pts:
             ga, gb = local2global(la, lb, spec.angle, (origin_pix[0] + p[0], origin_pix[1] + p[1]))
@@ -525,6 +533,52 @@ def channel_adjoint(tab: ChannelTables, y, alpha_axis, beta_axis, mode="exact", 
     return inter
 
 
+def slice_to_cube(tab: ChannelTables, data, alpha_axis, beta_axis, n_lambda):
+    """Channel.sliceToCube (:266-301): the data of pointing 0 sent back to the cube through the one-hot spectral
+    selector instead of the spectral PSF, then the reference's adjoint chain (slicing_t, transposed box sum,
+    interpolating gridding_t); planes outside the channel's window stay 0."""
+    Lin = tab.wslice[1] - tab.wslice[0]
+    na, nb = len(tab.local_alpha_axis), len(tab.local_beta_axis)
+    a0, a1, b0, b1 = tab.slit_slices[0]
+    y = np.asarray(data, dtype=np.float64).reshape(tab.oshape)
+    local = np.zeros((Lin, na, nb))
+    for s in range(tab.spec.n_slit):
+        over = np.repeat(y[0, s][:, :, None], tab.npix_slit_beta_width, axis=2)
+        bts = np.zeros((Lin, a1 - a0, b1 - b0))
+        bts[:, : tab.oshape[3] * tab.srf: tab.srf, :] = wblur_t(over, tab.wpsf_dirac)
+        local += slicing_t(tab, bts, s, (Lin, na, nb))
+    out = np.zeros((n_lambda, len(alpha_axis), len(beta_axis)))
+    out[tab.wslice[0]:tab.wslice[1]] = gridding_t_ref(tab, box_sum_fft_t(tab, local), 0, alpha_axis, beta_axis)
+    return out
+
+
+def realdata_cube_to_slice(tab0: ChannelTables, cube):
+    """Channel.realData_cubeToSlice (:303-309).  ``tab0`` is the channel built with the single pointing (0, 0);
+    every plane of ``cube`` (one per detector wavelength) is gridded, cut into slits with the edge weights, decimated
+    along alpha WITHOUT the box sum and summed over beta."""
+    g = gridding(tab0, np.asarray(cube, dtype=np.float64), 0)
+    out = np.zeros(tab0.oshape[1:])
+    for s in range(tab0.spec.n_slit):
+        out[s] = slicing(tab0, g, s)[:, : tab0.oshape[3] * tab0.srf: tab0.srf, :].sum(axis=2)
+    return out
+
+
+def realdata_slice_to_cube(tab0: ChannelTables, slices, cube_dim, alpha_axis, beta_axis):
+    """Channel.realData_sliceToCube (:311-336): each slit value spread evenly over the slit's beta columns, zero-stuffed
+    along alpha, slicing_t, correlation with the box kernel (``_otf_sr.conj()`` alone -- no ``decalf`` here), gridding_t."""
+    L = cube_dim[0]
+    na, nb = len(tab0.local_alpha_axis), len(tab0.local_beta_axis)
+    a0, a1, b0, b1 = tab0.slit_slices[0]
+    local = np.zeros((L, na, nb))
+    for s in range(tab0.spec.n_slit):
+        sl = np.zeros((L, a1 - a0, b1 - b0))
+        sl[:, ::tab0.srf] = np.repeat(np.asarray(slices)[s][:, :, None], tab0.npix_slit_beta_width, axis=2) / tab0.npix_slit_beta_width
+        local += slicing_t(tab0, sl, s, (L, na, nb))
+    otf_sr, _ = _box_filters(tab0)
+    st = idft(dft(local) * otf_sr.conj(), (na, nb))
+    return gridding_t_ref(tab0, st, 0, alpha_axis, beta_axis)
+
+
 # ----------------------------------------------------------------------------
 # Full operator (surfh/Models/spectroModel.py)
 # ----------------------------------------------------------------------------
@@ -669,6 +723,38 @@ def lcg(op, data, mu, mu_reg, x0, tol=1e-12, max_iter=10, refresh=50):
         nit = it + 1
         if np.sqrt(grad_norm[-1]) < x.size * tol:
             break
+    return {"x": x, "grad_norm": grad_norm, "nit": nit}
+
+
+def mmmg(op, data, mu, mu_reg, x0, tol=1e-12, max_iter=10):
+    """3MG as ``qmm.mmmg`` runs it on this path's three quadratic objectives (qmm 0.18.2 is absent: parity UNPINNED;
+    restated from the published algorithm, Chouzenoux, Idier & Moussaoui 2011, with qmm's loop structure [memory]).
+
+    Objectives: mu |y - A x|^2 (operator V = A), mu_reg |Dr x|^2, mu_reg |Dc x|^2.  Per iteration: grad from scratch,
+    ``grad_norm`` <- |grad|, stop when it is below size*tol, directions D = [-grad, move], operator images
+    V D = [V(-grad), (V D_prev) step_prev] per objective, step = -pinv(sum_k hyper_k (V_k D)^T (V_k D)) D^T grad
+    (the quadratic objective is its own majorant), move = D step, x += move.
+    Call site: surfh/Simulation/fusion_CT.py:194-225 (``function = mmmg``)."""
+    x = np.array(x0, dtype=np.float64, copy=True)
+    b = mu * op.adjoint(data)
+    ops = [(mu, op.forward), (mu_reg, diff_r), (mu_reg, diff_c)]
+    move = np.zeros_like(x)
+    vd = [np.stack([np.zeros_like(f(x)).ravel()] * 2, axis=1) for _, f in ops]
+    step = np.ones((2, 1))
+    grad_norm = []
+    nit = 0
+    for it in range(max_iter + 1):
+        grad = normal_apply(op, x, mu, mu_reg) - b
+        grad_norm.append(float(np.sqrt(np.sum(grad * grad))))
+        if it == max_iter or grad_norm[-1] < x.size * tol:
+            break
+        D = np.stack([-grad.ravel(), move.ravel()], axis=1)
+        vd = [np.stack([f(-grad).ravel(), (v @ step).ravel()], axis=1) for (_, f), v in zip(ops, vd)]
+        B = sum(h * (v.T @ v) for (h, _), v in zip(ops, vd))
+        step = -np.linalg.pinv(B) @ (D.T @ grad.ravel()).reshape(2, 1)
+        move = (D @ step).reshape(x.shape)
+        x = x + move
+        nit = it + 1
     return {"x": x, "grad_norm": grad_norm, "nit": nit}
 
 

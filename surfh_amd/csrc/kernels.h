@@ -63,6 +63,11 @@ int launch_cg_xupdate(hipStream_t s, float *x, const float *d, long n, const dou
 int launch_cg_dir(hipStream_t s, float *d, const float *r, long n, const double *rr_new, const double *rr_old);
 // r = b - q
 int launch_residual(hipStream_t s, float *r, const float *b, const float *q, long n);
+// out = a + beta b
+int launch_lincomb(hipStream_t s, float *out, const float *a, const float *b, long n, double beta);
+// 3MG move: mv = s0 d + s1 m ; x += mv ; m = mv ; qm = s0 qd + s1 qm ; r -= qm (when update_r)
+int launch_mmmg_update(hipStream_t s, float *x, float *r, const float *d, float *m, float *qm, const float *qd, long n, double s0,
+                       double s1, int update_r);
 // CG on independent planes ([nplanes][npix] arrays, per-plane scalars in double arrays of nplanes)
 int launch_dot_planes(hipStream_t s, const float *a, const float *b, int nplanes, long npix, double *out);
 int launch_cg_step_planes(hipStream_t s, float *x, float *r, const float *d, const float *q, int nplanes, long npix, const double *rr,

@@ -453,6 +453,28 @@ __global__ __launch_bounds__(TPB) void residual_kernel(float *__restrict__ r, co
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) r[i] = b[i] - q[i];
 }
 
+// ---- memory-gradient (3MG) vector kernels.  The subspace span{r, m} is handled in the basis [d, m] with d = r + beta m
+// Q-orthogonal to the previous move m; the operator images are carried by linearity.
+__global__ __launch_bounds__(TPB) void lincomb_kernel(float *__restrict__ out, const float *__restrict__ a,
+                                                      const float *__restrict__ b, long n, float beta) {
+    const long stride = (long)gridDim.x * TPB;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) out[i] = a[i] + beta * b[i];
+}
+
+__global__ __launch_bounds__(TPB) void mmmg_update_kernel(float *__restrict__ x, float *__restrict__ r, const float *__restrict__ d,
+                                                          float *__restrict__ m, float *__restrict__ qm,
+                                                          const float *__restrict__ qd, long n, float s0, float s1, int update_r) {
+    const long stride = (long)gridDim.x * TPB;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+        const float mv = s0 * d[i] + s1 * m[i];
+        const float qv = s0 * qd[i] + s1 * qm[i];
+        x[i] += mv;
+        m[i] = mv;
+        qm[i] = qv;
+        if (update_r) r[i] -= qv;
+    }
+}
+
 // ---- CG on a batch of independent planes (the 2-D deconvolution path, one problem per wavelength): every plane has
 // its own step and direction scalars.  One workgroup per plane; fp64 sums; a plane whose residual is already zero
 // (no data, or converged exactly) keeps still.
@@ -657,6 +679,17 @@ int launch_cg_xupdate(hipStream_t s, float *x, const float *d, long n, const dou
 
 int launch_cg_dir(hipStream_t s, float *d, const float *r, long n, const double *rr_new, const double *rr_old) {
     hipLaunchKernelGGL(cg_dir_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, d, r, n, rr_new, rr_old);
+    return (int)hipGetLastError();
+}
+
+int launch_lincomb(hipStream_t s, float *out, const float *a, const float *b, long n, double beta) {
+    hipLaunchKernelGGL(lincomb_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, out, a, b, n, (float)beta);
+    return (int)hipGetLastError();
+}
+
+int launch_mmmg_update(hipStream_t s, float *x, float *r, const float *d, float *m, float *qm, const float *qd, long n, double s0,
+                       double s1, int update_r) {
+    hipLaunchKernelGGL(mmmg_update_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, x, r, d, m, qm, qd, n, (float)s0, (float)s1, update_r);
     return (int)hipGetLastError();
 }
 

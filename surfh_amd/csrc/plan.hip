@@ -129,7 +129,7 @@ struct surfh_plan {
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
     // CG
-    float *cg_x = nullptr, *cg_r = nullptr, *cg_d = nullptr, *cg_q = nullptr, *cg_b = nullptr, *cg_y = nullptr;
+    float *cg_x = nullptr, *cg_r = nullptr, *cg_d = nullptr, *cg_q = nullptr, *cg_b = nullptr, *cg_y = nullptr, *cg_qm = nullptr, *cg_dd = nullptr;
     double *dscal = nullptr, *dscratch = nullptr;   // [8] device scalars, [1024] partial sums
     // profiling
     bool prof = false;
@@ -269,6 +269,8 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     c->nbs = d.n_beta_slit;
     if (c->Lin <= 0 || c->ws0 < 0 || c->ws1 > p->Lc) return fail("channel wslice (%d,%d) outside cube (Lc=%d)", c->ws0, c->ws1, p->Lc);
     if (c->P < 1 || c->S < 1 || c->Ldet < 1 || c->aout < 1 || c->srf < 1 || c->nbs < 1) return fail("bad channel dims");
+    const int box = d.box_len > 0 ? d.box_len : c->srf, bsh = d.box_len > 0 ? d.box_shift : 0;
+    if (box > c->na || bsh <= -c->na || bsh >= c->na) return fail("bad box window (len %d, shift %d)", box, bsh);
     if ((c->aout - 1) * c->srf >= c->nas) return fail("decimation (alpha_out-1)*srf=%d exceeds the slit alpha window %d", (c->aout - 1) * c->srf, c->nas);
     if (c->alpha0 < 0 || c->alpha0 + c->nas > c->na) return fail("slit alpha window outside the local grid");
     if (!d.slit_beta0 || !d.slit_weights || !d.grid_i0 || !d.grid_i1 || !d.grid_y0 || !d.grid_y1)
@@ -317,8 +319,8 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                     const double ws = d.slit_weights[(long)s * c->nbs + b];
                     std::vector<std::pair<int64_t, float>> row;
                     std::map<int64_t, double> acc;
-                    for (int r = 0; r < c->srf; ++r) {
-                        const int i = (c->alpha0 + a * c->srf + r) % c->na;
+                    for (int r = 0; r < box; ++r) {
+                        const int i = (c->alpha0 + a * c->srf + r + bsh + c->na) % c->na;
                         const long li = (long)pt * nloc + (long)i * c->nb + j;
                         const int i0 = d.grid_i0[li], i1 = d.grid_i1[li];
                         const double y0 = d.grid_y0[li], y1 = d.grid_y1[li];
@@ -369,7 +371,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
         // local row i' -> decimated rows a whose box window contains it
         std::vector<std::vector<int>> arow(c->na);
         for (int a = 0; a < c->aout; ++a)
-            for (int r = 0; r < c->srf; ++r) arow[(c->alpha0 + a * c->srf + r) % c->na].push_back(a);
+            for (int r = 0; r < box; ++r) arow[(c->alpha0 + a * c->srf + r + bsh + c->na) % c->na].push_back(a);
         HostEll t;
         const long npix = (long)p->Na * p->Nb;
         for (int ib = 0; ib < p->Nb; ++ib)
@@ -910,7 +912,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipSetDevice(p->dev);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
-                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y})
+                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
         hipFree(v);
     hipFree(p->dft3);
     hipFree(p->dscal);
@@ -939,7 +941,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     if (cfg->n_alpha < 2 || cfg->n_beta < 2 || cfg->n_lambda < 1) return fail("bad cube shape");
     if (cfg->n_channels < 0 || (cfg->n_channels > 0 && !cfg->channels)) return fail("bad channel list");
     if (cfg->n_channels == 0 && cfg->n_templates < 1) return fail("a plan without channels needs templates (Model_WCT)");
-    if (!cfg->sotf) return fail("sotf is NULL");
+    if (!cfg->sotf && cfg->n_templates > 0) return fail("sotf is NULL");      // NULL = no spatial blur, plane-wise plans only
     if (cfg->n_templates > 0 && !cfg->templates) return fail("templates is NULL");
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
@@ -1017,10 +1019,10 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             std::fill(row.begin(), row.end(), 0.f);
             for (int l = 0; l < p->Lown; ++l) {
                 if (p->planes[l] < 0) continue;     // alignment gap between segments: stays zero
-                const double *src = cfg->sotf + ((size_t)p->planes[l] * p->Na + a) * nkb * 2;
+                const double *src = cfg->sotf ? cfg->sotf + ((size_t)p->planes[l] * p->Na + a) * nkb * 2 : nullptr;
                 for (int k = 0; k < nkb; ++k) {
-                    row[(size_t)k * LP + l] = (float)src[2 * k];
-                    row[((size_t)p->KBP + k) * LP + l] = (float)src[2 * k + 1];
+                    row[(size_t)k * LP + l] = src ? (float)src[2 * k] : 1.f;
+                    row[((size_t)p->KBP + k) * LP + l] = src ? (float)src[2 * k + 1] : 0.f;
                 }
             }
             for (int c = 0; c < 2; ++c)
@@ -1445,6 +1447,100 @@ int surfh_cg_cb(surfh_plan *p, const float *y, double mu, double mu_reg, const f
 int surfh_cg(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
              int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
     return surfh_cg_cb(p, y, mu, mu_reg, x0, max_iter, tol, refresh, x, grad_norm, nit, nullptr, nullptr);
+}
+
+// ---- 3MG (majorize-minimize memory gradient, qmm.mmmg; selected by method != 'lcg' at fusion_CT.py:194-198) ----
+// For the quadratic objectives of this path the quadratic majorant is the criterion itself, so the MM step is the exact
+// minimiser of the criterion over span{-grad, previous move}.  qmm solves the 2x2 system in the basis [-grad, move] with the
+// operator applied to the gradient; in fp32 that form loses the conjugacy (the determinant r.Qr m.Qm - (r.Qm)^2 cancels) and
+// was measured to converge visibly slower than CG.  The same subspace is therefore spanned by [d, m], d = r + beta m made
+// Q-orthogonal to the previous move m with the carried image Qm, and the operator is applied to d: the 2x2 system
+//   [[d.Qd, d.Qm], [d.Qm, m.Qm]] step = [d.r, m.r]
+// is then nearly diagonal.  Same iterates in exact arithmetic, one normal-operator application per iteration; r is carried as
+// r -= Q move and recomputed from scratch every `refresh` iterations.  numpy's pinv cut (1e-15 of the unscaled matrix),
+// which in qmm drops the memory direction once |move|^2 / |grad|^2 < 1e-15, is not reproduced: the direction is dropped
+// only when the scaled system is singular.
+int surfh_mmmg(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+               int32_t refresh, float *x, double *grad_norm, int32_t *nit, surfh_cg_callback callback, void *user) {
+    if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
+    if (p->T <= 0) return fail("surfh_mmmg needs templates (the priors act on abundance maps)");
+    std::vector<float> hx;
+    if (callback) hx.resize((size_t)p->isize);
+    HIP_OK(hipSetDevice(p->dev));
+    if (ensure_cg(p)) return 1;
+    if (!p->cg_qm && (dev_alloc(&p->cg_qm, (size_t)p->isize) || dev_alloc(&p->cg_dd, (size_t)p->isize))) return 1;
+    hipStream_t s = p->stream;
+    const long n = p->isize;
+    float *r = p->cg_r, *m = p->cg_d, *d = p->cg_dd, *qd = p->cg_q, *qm = p->cg_qm;
+    auto Q = [&](const float *v, float *out) -> int {
+        if (normal_dev(p, v, out, mu)) return 1;
+        if (mu_reg != 0.0) {
+            Prof pr(p, "prior_add");
+            LAUNCH_OK(launch_prior_add(s, v, out, p->T, p->Na, p->Nb, (float)mu_reg));
+        }
+        return 0;
+    };
+    HIP_OK(hipMemcpyAsync(p->io_y, y, p->osize * sizeof(float), hipMemcpyHostToDevice, s));
+    if (adjoint_dev(p, p->io_y, p->cg_b, false)) return 1;
+    if (mu != 1.0) LAUNCH_OK(launch_scale(s, p->cg_b, n, (float)mu));
+    if (x0)
+        HIP_OK(hipMemcpyAsync(p->cg_x, x0, n * sizeof(float), hipMemcpyHostToDevice, s));
+    else
+        LAUNCH_OK(launch_fill_zero(s, p->cg_x, n));
+    LAUNCH_OK(launch_fill_zero(s, m, n));
+    LAUNCH_OK(launch_fill_zero(s, qm, n));
+    if (Q(p->cg_x, qd)) return 1;
+    LAUNCH_OK(launch_residual(s, r, p->cg_b, qd, n));
+    double h[6];
+    *nit = 0;
+    for (int it = 0;; ++it) {
+        // h0 = r.r (stopping quantity and trace entry), h1 = r.Qm, h2 = m.Qm
+        LAUNCH_OK(launch_dot(s, r, r, n, p->dscratch, p->dscal + 0));
+        LAUNCH_OK(launch_dot(s, r, qm, n, p->dscratch, p->dscal + 1));
+        LAUNCH_OK(launch_dot(s, m, qm, n, p->dscratch, p->dscal + 2));
+        HIP_OK(hipMemcpyAsync(h, p->dscal, 3 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        grad_norm[it] = std::sqrt(h[0]);
+        if (it > 0 && callback) {
+            HIP_OK(hipMemcpyAsync(hx.data(), p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            if (callback(user, it, grad_norm, hx.data())) break;
+            HIP_OK(hipSetDevice(p->dev));
+        }
+        if (it >= max_iter || grad_norm[it] < (double)n * tol) break;
+        const double mQm = h[2], beta = mQm > 0.0 ? -h[1] / mQm : 0.0;
+        LAUNCH_OK(launch_lincomb(s, d, r, m, n, beta));
+        if (Q(d, qd)) return 1;
+        LAUNCH_OK(launch_dot(s, d, qd, n, p->dscratch, p->dscal + 3));
+        LAUNCH_OK(launch_dot(s, d, qm, n, p->dscratch, p->dscal + 4));
+        LAUNCH_OK(launch_dot(s, d, r, n, p->dscratch, p->dscal + 5));
+        LAUNCH_OK(launch_dot(s, m, r, n, p->dscratch, p->dscal + 6));
+        HIP_OK(hipMemcpyAsync(h, p->dscal + 3, 4 * sizeof(double), hipMemcpyDeviceToHost, s));
+        HIP_OK(hipStreamSynchronize(s));
+        const double dQd = h[0], dQm = h[1], dr = h[2], mr = h[3];
+        if (!(dQd > 0.0)) return fail("3MG: non-positive curvature d.Qd = %g at iteration %d", dQd, it);
+        double s0 = dr / dQd, s1 = 0.0;
+        if (mQm > 0.0) {
+            const double c = dQm / std::sqrt(dQd * mQm), det = 1.0 - c * c;      // scaled 2x2 system
+            if (det > 1e-12) {
+                s0 = (dr / dQd - c * mr / std::sqrt(dQd * mQm)) / det;
+                s1 = (mr / mQm - c * dr / std::sqrt(dQd * mQm)) / det;
+            }
+        }
+        const bool fresh = refresh > 0 && it % refresh == 0;
+        {
+            Prof pr(p, "mmmg_update");
+            LAUNCH_OK(launch_mmmg_update(s, p->cg_x, r, d, m, qm, qd, n, s0, s1, fresh ? 0 : 1));
+        }
+        if (fresh) {
+            if (Q(p->cg_x, qd)) return 1;
+            LAUNCH_OK(launch_residual(s, r, p->cg_b, qd, n));
+        }
+        *nit = it + 1;
+    }
+    HIP_OK(hipMemcpyAsync(x, p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
 }
 
 // ---- CG on independent planes: the 2-D deconvolution path (criterion_2D.py:60-250 per image, batched over wavelength)

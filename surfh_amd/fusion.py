@@ -1,9 +1,9 @@
 """Regularised least-squares fusion by linear CG on top of ``spectroSigRLSCT``.
 
 * ``QuadCriterion_MRS`` mirrors the reference's criterion class
-  (surfh/Simulation/fusion_CT.py:66-265): same constructor, ``run_method('lcg', ...)``,
-  ``get_crit_val``; the solver it drives is the library's device-resident CG
-  (``qmm.lcg`` restated, see include/surfh_amd.h:surfh_cg).
+  (surfh/Simulation/fusion_CT.py:66-265): same constructor, ``run_method('lcg' | 'mmmg', ...)``,
+  ``get_crit_val``; the solvers it drives are the library's device-resident CG and 3MG
+  (``qmm.lcg`` / ``qmm.mmmg`` restated, see include/surfh_amd.h:surfh_cg, surfh_mmmg).
 * ``DistributedFusion`` is the multi-GPU form: one process per GPU, each rank owns a set of
   (band, pointings) units, x/r/d are replicated, and the only exchange per iteration is one
   RCCL all-reduce (sum) of the partial normal-equation product mu * A_r^T A_r d  ([T, Na, Nb] fp32)
@@ -49,8 +49,7 @@ class QuadCriterion_MRS:
         ``get_crit_val`` itself to qmm as the callback, which receives an OptimizeResult and cannot work -- here the
         criterion of every iterate is recorded in ``L_crit_val`` instead."""
         assert isinstance(self.mu_reg, (int, float))       # fusion_CT.py:119
-        if method != "lcg":
-            raise NotImplementedError("only method='lcg' is built (mmmg is out of the hot-path scope)")
+        solver = self.model_spectro.cg if method == "lcg" else self.model_spectro.mmmg     # fusion_CT.py:194-198
         if isinstance(value_init, (int, float)):
             init = np.ones(self.shape_of_output) * value_init
         else:
@@ -85,10 +84,11 @@ class QuadCriterion_MRS:
         else:
             callback = None
         t0 = time.time()
-        x, gn, nit = self.model_spectro.cg(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
-                                           max_iter=maximum_iterations, tol=tolerance, callback=callback)
+        x, gn, nit = solver(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
+                            max_iter=maximum_iterations, tol=tolerance, callback=callback)
+        last = np.sqrt(gn[-1]) if method == "lcg" else gn[-1]      # lcg traces r.r, mmmg |grad|
         res = OptimizeResult(x=x.ravel(), grad_norm=list(gn), nit=nit,
-                             success=bool(np.sqrt(gn[-1]) < x.size * tolerance), time=time.time() - t0)
+                             success=bool(last < x.size * tolerance), time=time.time() - t0)
         if self.printing:
             print(f"Total time needed for {method} :", round(res.time, 3))
         return res

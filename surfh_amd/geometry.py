@@ -146,12 +146,20 @@ class ChannelGeometry:
 
     def __init__(self, instr: instru.IFU, alpha_axis, beta_axis, wavel_axis, srf: int,
                  pointings: instru.CoordList, step_degree: float, gridding: str = "bilinear",
-                 lam_slice=None):
+                 lam_slice=None, psf_type: str = "mrs", box=None, beta_sum: bool = False, full_window: bool = False):
         """``lam_slice = (i, n)`` keeps only the i-th of n contiguous parts of the channel's wavelength window
-        (multi-GPU: a band's lambda range shared by n ranks; the partial outputs add up to the band's output)."""
+        (multi-GPU: a band's lambda range shared by n ranks; the partial outputs add up to the band's output).
+
+        The last four arguments select the variants the reference's slice <-> cube projections use
+        (spectroModelChannel.py:266-336): ``psf_type='dirac'`` the one-hot spectral selector ``wpsf_dirac``;
+        ``box=(len, shift)`` another alpha window per detector sample (see ``surfh_channel_desc.box_len``);
+        ``beta_sum`` no spectral blur, the slit's beta columns are summed; ``full_window`` every plane of the cube is
+        observed (the real-data cubes live on the detector's wavelength axis)."""
         if gridding not in ("bilinear", "nn", "nn_ref"):
             raise ValueError("gridding must be 'bilinear', 'nn' or 'nn_ref'")
         self.gridding_mode = gridding
+        self.psf_type, self.box, self.beta_sum = psf_type, box, beta_sum
+        self.raw_instr, self.raw_pointings = instr, pointings
         self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
         self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
         self.global_wavelength_axis = np.asarray(wavel_axis, dtype=np.float64)
@@ -163,7 +171,7 @@ class ChannelGeometry:
             step_degree, alpha_margin=5 * step_degree, beta_margin=5 * step_degree)
         self.slicer = Slicer(self.instr, self.global_wavelength_axis, self.alpha_axis, self.beta_axis,
                              self.local_alpha_axis, self.local_beta_axis, srf)
-        self.wslice = self.instr.wslice(self.global_wavelength_axis, 0.1)
+        self.wslice = slice(0, len(self.global_wavelength_axis)) if full_window else self.instr.wslice(self.global_wavelength_axis, 0.1)
         self.band_wslice = self.wslice
         self.lam_slice = lam_slice
         if lam_slice is not None:
@@ -179,7 +187,8 @@ class ChannelGeometry:
                 raise ValueError(f"bad lam_slice {lam_slice} for a window of {lin} planes")
             self.wslice = slice(ws0 + a, ws0 + b)
         n_out = ceil(self.slicer.npix_slit_alpha_width / srf)
-        self.oshape = (len(self.pointings), self.instr.n_slit, len(self.instr.wavel_axis), n_out)
+        n_det = (self.wslice.stop - self.wslice.start) if beta_sum else len(self.instr.wavel_axis)
+        self.oshape = (len(self.pointings), self.instr.n_slit, n_det, n_out)
         self.slices_shape = (len(self.pointings), self.instr.n_slit, n_out)
         self.local_im_shape = (len(self.local_alpha_axis), len(self.local_beta_axis))
         self.imshape = (len(self.alpha_axis), len(self.beta_axis))
@@ -201,7 +210,7 @@ class ChannelGeometry:
             # always evaluated on the band's full window (its normalisation runs over that axis), then cut
             full = self.instr.spectral_psf(
                 b - np.mean(b), self.global_wavelength_axis[self.band_wslice],
-                arcsec2micron=self.instr.wavel_step / self.instr.det_pix_size, type="mrs")
+                arcsec2micron=self.instr.wavel_step / self.instr.det_pix_size, type=self.psf_type)
             o = self.wslice.start - self.band_wslice.start
             self._wpsf = np.ascontiguousarray(full[:, o: o + (self.wslice.stop - self.wslice.start), :])
         return self._wpsf
@@ -272,7 +281,8 @@ class ChannelGeometry:
             grid_i1=np.ascontiguousarray(np.stack([x[1] for x in g]), dtype=np.int32),
             grid_y0=np.ascontiguousarray(np.stack([x[2] for x in g]), dtype=np.float64),
             grid_y1=np.ascontiguousarray(np.stack([x[3] for x in g]), dtype=np.float64),
-            wpsf=np.ascontiguousarray(self.wpsf, dtype=np.float64),
+            wpsf=None if self.beta_sum else np.ascontiguousarray(self.wpsf, dtype=np.float64),
+            box_len=0 if self.box is None else int(self.box[0]), box_shift=0 if self.box is None else int(self.box[1]),
         )
         if with_ref:
             r = [self.gridt_tables(p) for p in range(P)]

@@ -226,11 +226,7 @@ class SpectralBlur:
         out = np.pi * gl / ext * np.sinc(np.pi * gl * ((oa - scale * bt) / ext - 1)) ** 2
         out /= np.sum(out, axis=1, keepdims=True)
         if type == "dirac":
-            peak = np.zeros_like(out)
-            for i in range(out.shape[2]):
-                for k in range(out.shape[0]):
-                    peak[k, np.where(out[k, :, i] == np.max(out[k, :, i])), i] = 1
-            out = peak
+            out = (out == out.max(axis=1, keepdims=True)).astype(out.dtype)      # one-hot at the peak of every (lambda', beta)
         return out[:, m - 1: -m + 1, :]
 
 

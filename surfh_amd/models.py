@@ -30,11 +30,65 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr())
 
 
+class Channel(ChannelGeometry):
+    """One channel of the model, as ``model.channels[k]`` (surfh.Models.spectroModelChannel.Channel): the geometry
+    plus the reference's slice <-> cube projections its drivers use to look at data and to initialise
+    (scripts/fusion/*.py).  Each projection is the library's own gather / GEMM / scatter chain on the GPU, run on a
+    small single-channel plane-wise plan built on first use with the variant tables of ``ChannelGeometry``."""
+    device = 0
+
+    def _aux(self, key, wavel_axis, pointings, **opts):
+        cache = self.__dict__.setdefault("_aux_ops", {})
+        if key not in cache:
+            cache[key] = spectroSigRLSCT(None, None, self.alpha_axis, self.beta_axis, wavel_axis, [self.raw_instr],
+                                         self.step_degree, [instru.CoordList(pointings)], device=self.device,
+                                         gridding=self.gridding_mode, channel_opts=opts)
+        return cache[key]
+
+    def close(self):
+        for op in self.__dict__.pop("_aux_ops", {}).values():
+            op.close()
+
+    def sliceToCube(self, data):
+        """spectroModelChannel.py:266-301: the data of pointing 0 back in the cube -- every detector sample goes to the
+        wavelength plane where its spectral response peaks (``wpsf_dirac``), then the reference's adjoint chain
+        (slit weights, transposed box sum, interpolating ``gridding_t``).  Returns [len(wavelength_axis), Na, Nb]."""
+        if self.lam_slice is not None:
+            raise ValueError("sliceToCube is defined on a whole channel, not on a lambda part")
+        op = self._aux("s2c", self.global_wavelength_axis, [self.raw_pointings[0]], psf_type="dirac")
+        y0 = np.asarray(data, dtype=np.float64).reshape(self.oshape)[0]
+        return op.adjoint_ref(y0)
+
+    def realData_cubeToSlice(self, cube):
+        """spectroModelChannel.py:303-309: a cube on the detector's wavelength axis -> [n_slit, L, n_alpha_out]:
+        gridding at pointing (0, 0), slit windows with their edge weights, plain alpha decimation, sum over beta."""
+        cube = np.asarray(cube)
+        if cube.shape != (self.oshape[2],) + self.imshape:
+            raise ValueError(f"cube shape {cube.shape} != {(self.oshape[2],) + self.imshape}")
+        op = self._aux("c2s", np.asarray(self.raw_instr.wavel_axis, dtype=np.float64), [instru.Coord(0, 0)],
+                       beta_sum=True, full_window=True, box=(1, 0))
+        L, (S, A) = self.oshape[2], (self.oshape[1], self.oshape[3])
+        return op.forward(cube).reshape(L, S, A).transpose(1, 0, 2).copy()          # the plan's beta-sum output is [l][s][a]
+
+    def realData_sliceToCube(self, slices, cube_dim):
+        """spectroModelChannel.py:311-336: slit values spread evenly over the slit's beta columns, zero-stuffed along
+        alpha, correlated with the box kernel (``_otf_sr.conj()``, no ``decalf``) and back-interpolated at pointing (0, 0)."""
+        cube_dim = tuple(int(v) for v in cube_dim)
+        if cube_dim != (self.oshape[2],) + self.imshape:
+            raise ValueError(f"cube_dim {cube_dim} != {(self.oshape[2],) + self.imshape}")
+        op = self._aux("s2c_rd", np.asarray(self.raw_instr.wavel_axis, dtype=np.float64), [instru.Coord(0, 0)],
+                       beta_sum=True, full_window=True, box=(self.srf, -int((self.srf - 1) / 2)))
+        s = np.asarray(slices, dtype=np.float64).reshape(self.oshape[1:]) / self.slicer.npix_slit_beta_width
+        return op.adjoint_ref(np.ascontiguousarray(s.transpose(1, 0, 2)))
+
+
 class spectroSigRLSCT(LinOp):
     def __init__(self, sotf, templates, alpha_axis, beta_axis, wavelength_axis, instrs: List[instru.IFU],
                  step_degree: float, pointings: Sequence[instru.CoordList], *, device: int = 0,
                  channels: Optional[Sequence[int]] = None, with_ref: bool = True, stream: Optional[int] = None,
-                 split_k_forward: int = 0, gridding: str = "bilinear", lam_slices=None):
+                 split_k_forward: int = 0, gridding: str = "bilinear", lam_slices=None, channel_opts: Optional[dict] = None):
+        """``sotf=None`` (plane-wise plans only, ``templates=None``) means no spatial blur; ``channel_opts`` are the
+        ``ChannelGeometry`` variants of the slice <-> cube projections (see ``Channel`` below)."""
         self.sotf = sotf
         self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
         self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
@@ -46,10 +100,12 @@ class spectroSigRLSCT(LinOp):
         self.instrs = [i.pix(step_degree) for i in instrs]
         self.srfs = instru.get_srf([i.det_pix_size for i in instrs], step_degree * 3600)
         # every channel's geometry is known to every rank; `channels` selects the ones this plan owns
-        self.all_channels = [ChannelGeometry(ins, self.alpha_axis, self.beta_axis, self.wavelength_axis, srf,
-                                             pointings[k], step_degree, gridding=gridding,
-                                             lam_slice=None if lam_slices is None else lam_slices[k])
+        self.all_channels = [Channel(ins, self.alpha_axis, self.beta_axis, self.wavelength_axis, srf,
+                                     pointings[k], step_degree, gridding=gridding,
+                                     lam_slice=None if lam_slices is None else lam_slices[k], **(channel_opts or {}))
                              for k, (srf, ins) in enumerate(zip(self.srfs, instrs))]
+        for c in self.all_channels:
+            c.device = device
         self.owned = list(range(len(instrs))) if channels is None else [int(c) for c in channels]
         self.channels = [self.all_channels[k] for k in self.owned]
         self.list_wslice = [c.wslice for c in self.channels]
@@ -62,8 +118,10 @@ class spectroSigRLSCT(LinOp):
         super().__init__(ishape=(lead,) + self.imshape, oshape=(int(self._idx[-1]),))
 
         nkb = self.imshape[1] // 2 + 1
-        sotf_c = np.ascontiguousarray(sotf, dtype=np.complex128)
-        if sotf_c.shape != (self.cube_shape[0], self.imshape[0], nkb):
+        if sotf is None and self.lmm:
+            raise ValueError("sotf=None (no spatial blur) is only defined without templates")
+        sotf_c = None if sotf is None else np.ascontiguousarray(sotf, dtype=np.complex128)
+        if sotf_c is not None and sotf_c.shape != (self.cube_shape[0], self.imshape[0], nkb):
             raise ValueError(f"sotf shape {sotf_c.shape} != {(self.cube_shape[0], self.imshape[0], nkb)}")
         if self.lmm and self.templates.shape[1] != self.cube_shape[0]:
             raise ValueError("templates must be [T, len(wavelength_axis)]")
@@ -81,7 +139,8 @@ class spectroSigRLSCT(LinOp):
             d.slit_weights = _lib.dptr(t["slit_weights"])
             d.grid_i0, d.grid_i1 = _lib.iptr(t["grid_i0"]), _lib.iptr(t["grid_i1"])
             d.grid_y0, d.grid_y1 = _lib.dptr(t["grid_y0"]), _lib.dptr(t["grid_y1"])
-            d.wpsf = _lib.dptr(t["wpsf"])
+            d.wpsf = None if t["wpsf"] is None else _lib.dptr(t["wpsf"])
+            d.box_len, d.box_shift = t["box_len"], t["box_shift"]
             if with_ref:
                 d.gt_i0, d.gt_i1 = _lib.iptr(t["gt_i0"]), _lib.iptr(t["gt_i1"])
                 d.gt_y0, d.gt_y1 = _lib.dptr(t["gt_y0"]), _lib.dptr(t["gt_y1"])
@@ -90,7 +149,7 @@ class spectroSigRLSCT(LinOp):
         cfg.n_alpha, cfg.n_beta, cfg.n_lambda = self.imshape[0], self.imshape[1], self.cube_shape[0]
         cfg.n_templates = self.templates.shape[0] if self.lmm else 0
         cfg.templates = _lib.dptr(self.templates) if self.lmm else None
-        cfg.sotf = sotf_c.view(np.float64).ctypes.data_as(_lib.c_double_p)
+        cfg.sotf = None if sotf_c is None else sotf_c.view(np.float64).ctypes.data_as(_lib.c_double_p)
         cfg.n_channels = len(self.channels)
         cfg.channels = descs
         cfg.device = device
@@ -105,6 +164,8 @@ class spectroSigRLSCT(LinOp):
 
     # ---- life cycle -----------------------------------------------------------------------
     def close(self):
+        for c in getattr(self, "all_channels", []):
+            c.close()
         if getattr(self, "_plan", None):
             self._L.surfh_plan_destroy(self._plan)
             self._plan = None
@@ -192,6 +253,14 @@ class spectroSigRLSCT(LinOp):
         """Device-resident linear CG (qmm.lcg restated).  ``callback(it, grad_norm, x)`` -- the per-iteration callback
         of ``qmm.lcg`` (fusion_CT.py:194-225) -- receives the 1-based iteration, the grad_norm trace so far and the
         current iterate ``[T,Na,Nb]``; it may call ``forward`` / ``adjoint`` on this model; a truthy return stops."""
+        return self._solve(self._L.surfh_cg_cb, data, mu, mu_reg, x0, max_iter, tol, refresh, callback)
+
+    def mmmg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):
+        """Device-resident 3MG (qmm.mmmg restated for quadratic objectives; the reference's ``method='mmmg'``,
+        fusion_CT.py:194-198).  Same arguments as ``cg``; ``grad_norm`` holds |grad| (not squared) of every iterate."""
+        return self._solve(self._L.surfh_mmmg, data, mu, mu_reg, x0, max_iter, tol, refresh, callback)
+
+    def _solve(self, fn, data, mu, mu_reg, x0, max_iter, tol, refresh, callback):
         y = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
         if y.size != self.osize:
             raise ValueError("data size mismatch")
@@ -211,7 +280,7 @@ class spectroSigRLSCT(LinOp):
                 return 1
 
         cb = _lib.CG_CALLBACK(tramp) if callback is not None else _lib.CG_CALLBACK()
-        _lib.check(self._L.surfh_cg_cb(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
+        _lib.check(fn(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
                                        _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol),
                                        int(refresh), _lib.fptr(x), _lib.dptr(gn), C.byref(nit), cb, None))
         if err:

@@ -257,8 +257,29 @@ def mixing_st():
                         TST=np.asarray(m.TST))
 
 
+def projections():
+    """Channel.sliceToCube / realData_cubeToSlice / realData_sliceToCube (spectroModelChannel.py:266-336) on config 1."""
+    ns = rh.load()
+    cfg = problems.config1()
+    rm = ref_model(ns, cfg)
+    ch = rm.channels[0]
+    y = rm.forward(cfg["maps"])
+    s2c = ch.sliceToCube(y)
+    L = ch.oshape[2]
+    cube = np.random.default_rng(7).random((L,) + rm.imshape)
+    c2s = ch.realData_cubeToSlice(cube)
+    back = ch.realData_sliceToCube(c2s, cube.shape)
+    sel, sel_rd = np.array([13, 14, 62, 114]), np.array([0, 20, 47])      # plane 14 is empty: only the peak planes receive data
+    np.savez_compressed(os.path.join(HERE, "channel_projections.npz"), cube_seed=np.int64(7),
+                        s2c_sel=s2c[sel], s2c_plane_sums=s2c.sum(axis=(1, 2)), s2c_abs_sums=np.abs(s2c).sum(axis=(1, 2)), sel=sel,
+                        c2s=c2s, s2c_rd_sel=back[sel_rd], s2c_rd_plane_sums=back.sum(axis=(1, 2)), sel_rd=sel_rd,
+                        wpsf_dirac_argmax=np.argmax(ch.wpsf_dirac, axis=1).astype(np.int32),
+                        wpsf_dirac_count=ch.wpsf_dirac.sum(axis=1).astype(np.int32))
+
+
 if __name__ == "__main__":
     main()
+    projections()
     blurred()
     wct()
     mixing_st()

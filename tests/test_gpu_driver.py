@@ -49,6 +49,51 @@ def test_cg_callback_trace(setup):
         m.cg(y, mu=1.0, mu_reg=5e3, max_iter=2, callback=lambda it, g, xx: 1 / 0)
 
 
+def test_mmmg_matches_oracle_and_cg(setup, capsys):
+    """The reference's other solver choice (fusion_CT.py:194-198 -> qmm.mmmg) against the oracle's restatement, and against
+    CG: on this quadratic criterion both produce the same iterates."""
+    from surfh_amd.fusion import QuadCriterion_MRS
+    cfg, om, m, y = setup
+    mu, mur, nit = 1.0, 5e3, 8
+    x0 = np.ones(m.ishape) * 0.5
+    ref = orc.mmmg(om, y, mu, mur, x0, max_iter=nit)
+    x, gn, n = m.mmmg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=nit)
+    assert n == nit and gn.shape == (nit + 1,)
+    gr = np.array(ref["grad_norm"])
+    # fp32 operator vs the float64 restatement of qmm.mmmg: the same accuracy as CG has against qmm.lcg
+    assert rel(x, ref["x"]) < 1e-4 and float(np.max(np.abs(gn - gr) / gr)) < 2e-4
+    xc, gc, _ = m.cg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=nit)
+    assert rel(x, xc) < 1e-4 and float(np.max(np.abs(gn ** 2 - gc) / gc)) < 1e-3
+    # refresh every iteration (gradient always from scratch, as qmm does) gives the same path
+    xf, gf, _ = m.mmmg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=nit, refresh=1)
+    assert rel(xf, x) < 1e-4
+    # from x0 = 0 the float64 restatement itself leaves the CG path at iterations 7-8 (numpy's pinv cut drops the
+    # memory direction once |move|^2 / |grad|^2 < 1e-15, see oracle mmmg vs lcg); the device solver, which scales the 2x2
+    # system, stays on it
+    z = np.zeros(m.ishape)
+    xz, gz, _ = m.mmmg(y, mu=mu, mu_reg=mur, x0=z, max_iter=nit)
+    rz, rl = orc.mmmg(om, y, mu, mur, z, max_iter=nit), orc.lcg(om, y, mu, mur, z, max_iter=nit)
+    assert float(np.max(np.abs(gz[:6] - rz["grad_norm"][:6]) / rz["grad_norm"][:6])) < 2e-4
+    assert float(np.max(np.abs(gz - np.sqrt(rl["grad_norm"])) / np.sqrt(rl["grad_norm"]))) < 2e-4 and rel(xz, rl["x"]) < 2e-4
+    # long run: converges like CG (the literal [-grad, move] basis in fp32 does not: DESIGN.md)
+    xl, gl, _ = m.mmmg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=40)
+    xcl, gcl, _ = m.cg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=40)
+    jl, jc = orc.crit_val(om, y, xl, mu, mur), orc.crit_val(om, y, xcl, mu, mur)
+    assert abs(jl - jc) / jc < 1e-4 and rel(xl, xcl) < 2e-3
+    # callback, early stop, tolerance stop
+    seen = []
+    x3, g3, n3 = m.mmmg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=nit, callback=lambda it, g, xx: seen.append(it) or it == 3)
+    assert n3 == 3 and seen == [1, 2, 3] and np.array_equal(g3, gn[:4])
+    xt, gt, nt = m.mmmg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=nit, tol=gn[4] * 1.0001 / x.size)
+    assert nt == 4 and np.array_equal(gt, gn[:5])
+    # through the criterion class, as the reference's drivers select it
+    q = QuadCriterion_MRS(mu, y, m, mur)
+    res = q.run_method("mmmg", nit, value_init=0.5)
+    assert res.nit == nit and rel(res.x.reshape(m.ishape), x) == 0.0
+    c = [orc.crit_val(om, y, m.mmmg(y, mu=mu, mu_reg=mur, x0=x0, max_iter=k)[0], mu, mur) for k in (1, 4, 8)]
+    assert c[0] > c[1] > c[2]
+
+
 def test_criterion_trace_modes(setup, capsys):
     """fusion_CT.py:163-225: criterion at iterations 1, 6, 11, ... when both flags are set."""
     from surfh_amd.fusion import QuadCriterion_MRS

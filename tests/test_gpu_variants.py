@@ -246,3 +246,35 @@ def test_plane_wise_cg_2d_deconvolution():
         crit.run_method("mmmg")
     m.close()
     m1.close()
+
+
+def test_slice_cube_projections():
+    """the reference's slice <-> cube projections (spectroModelChannel.py:266-336) through
+    ``model.channels[k]``, against the golden vectors of the real reference and the oracle."""
+    cfg = problems.config1()
+    om = problems.oracle_model(cfg, box="direct")
+    g1 = np.load(os.path.join(G, "config1_chain.npz"))
+    g = np.load(os.path.join(G, "channel_projections.npz"))
+    m = build_model(cfg)
+    ch = m.channels[0]
+    y = g1["y"]
+    s2c = ch.sliceToCube(y)
+    ref = orc.slice_to_cube(om.channels[0], y, cfg["alpha_axis"], cfg["beta_axis"], len(cfg["wavel"]))
+    assert s2c.shape == ref.shape == (len(cfg["wavel"]), 64, 64)
+    e = dict(s2c=rel(s2c, ref), s2c_gold=rel(s2c[g["sel"]], g["s2c_sel"]))
+    assert np.array_equal(np.abs(s2c).sum(axis=(1, 2)) > 0, g["s2c_abs_sums"] > 0)      # empty planes are exactly zero
+    tab0 = orc.build_channel(cfg["specs"][0], cfg["alpha_axis"], cfg["beta_axis"], cfg["wavel"], cfg["step_deg"], [(0.0, 0.0)])
+    cube = np.random.default_rng(int(g["cube_seed"])).random((ch.oshape[2], 64, 64))
+    c2s = ch.realData_cubeToSlice(cube)
+    assert c2s.shape == g["c2s"].shape
+    e.update(c2s=rel(c2s, orc.realdata_cube_to_slice(tab0, cube)), c2s_gold=rel(c2s, g["c2s"]))
+    back = ch.realData_sliceToCube(g["c2s"], cube.shape)
+    e.update(back=rel(back, orc.realdata_slice_to_cube(tab0, g["c2s"], cube.shape, cfg["alpha_axis"], cfg["beta_axis"])),
+             back_gold=rel(back[g["sel_rd"]], g["s2c_rd_sel"]))
+    print(e)
+    assert max(e.values()) < TOL
+    with pytest.raises(ValueError):
+        ch.realData_cubeToSlice(cube[1:])
+    # the operator itself is untouched by the auxiliary plans
+    assert rel(m.forward(cfg["maps"]), y) < TOL
+    m.close()

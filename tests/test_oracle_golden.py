@@ -161,6 +161,59 @@ def test_lcg_matches_dense_solve():
     assert c[0] > c[1] > c[2]
 
 
+def test_slice_cube_projections_match_reference(c1):
+    """Channel.sliceToCube / realData_cubeToSlice / realData_sliceToCube (spectroModelChannel.py:266-336)."""
+    cfg, om, g1 = c1
+    g = np.load(os.path.join(G, "channel_projections.npz"))
+    tab = om.channels[0]
+    assert np.array_equal(tab.wpsf_dirac.sum(axis=1), g["wpsf_dirac_count"])          # one-hot selector: bit-exact
+    assert np.array_equal(np.argmax(tab.wpsf_dirac, axis=1), g["wpsf_dirac_argmax"])
+    s2c = orc.slice_to_cube(tab, g1["y"], cfg["alpha_axis"], cfg["beta_axis"], len(cfg["wavel"]))
+    # the reference casts the repeated data to float32 before the spectral step (:283): 1e-7 is that rounding
+    assert rel(s2c[g["sel"]], g["s2c_sel"]) < 2e-7 and rel(s2c.sum(axis=(1, 2)), g["s2c_plane_sums"]) < 2e-7
+    assert np.array_equal(np.abs(s2c).sum(axis=(1, 2)) > 0, g["s2c_abs_sums"] > 0)     # only the peak planes receive data
+    tab0 = orc.build_channel(cfg["specs"][0], cfg["alpha_axis"], cfg["beta_axis"], cfg["wavel"], cfg["step_deg"], [(0.0, 0.0)])
+    cube = np.random.default_rng(int(g["cube_seed"])).random((tab0.oshape[2], 64, 64))
+    c2s = orc.realdata_cube_to_slice(tab0, cube)
+    assert c2s.shape == g["c2s"].shape and rel(c2s, g["c2s"]) < 1e-14
+    back = orc.realdata_slice_to_cube(tab0, g["c2s"], cube.shape, cfg["alpha_axis"], cfg["beta_axis"])
+    assert rel(back[g["sel_rd"]], g["s2c_rd_sel"]) < 1e-13 and rel(back.sum(axis=(1, 2)), g["s2c_rd_plane_sums"]) < 1e-13
+
+
+def test_mmmg_matches_dense_solve_and_lcg_iterates():
+    """qmm.mmmg is absent (parity unpinned): the restated 3MG reaches the dense solution, and on a quadratic criterion
+    its iterates are those of linear CG (both minimise over the same Krylov subspaces)."""
+    rng = np.random.default_rng(3)
+
+    class Small:
+        ishape = (2, 5, 6)
+        A = rng.standard_normal((80, 60))
+
+        def forward(self, x):
+            return self.A @ x.ravel()
+
+        def adjoint(self, y):
+            return (self.A.T @ y).reshape(self.ishape)
+
+    op = Small()
+    y = rng.standard_normal(80)
+    mu, mur = 1.3, 0.7
+    x0 = rng.standard_normal(op.ishape)
+    res = orc.mmmg(op, y, mu, mur, x0, tol=1e-14, max_iter=200)
+    Q = np.zeros((60, 60))
+    for k in range(60):
+        e = np.zeros(60); e[k] = 1
+        Q[:, k] = orc.normal_apply(op, e.reshape(op.ishape), mu, mur).ravel()
+    xs = np.linalg.solve(Q, (mu * op.adjoint(y)).ravel())
+    assert rel(res["x"].ravel(), xs) < 1e-9
+    assert len(res["grad_norm"]) == res["nit"] + 1 and res["grad_norm"][-1] < 60 * 1e-14 * 10
+    for k in (1, 2, 5, 9):
+        a = orc.mmmg(op, y, mu, mur, x0, max_iter=k)
+        b = orc.lcg(op, y, mu, mur, x0, max_iter=k)
+        assert a["nit"] == k and rel(a["x"], b["x"]) < 1e-9
+        assert abs(a["grad_norm"][-1] ** 2 - b["grad_norm"][-1]) < 1e-8 * b["grad_norm"][0]      # |grad| vs r.r
+
+
 def test_nn_indices_match_reference_ckdtree():
     """NN gridding index tables (Channel.precompute_mask recipe) against the reference's cKDTree output."""
     cfg = problems.config1()
