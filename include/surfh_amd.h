@@ -161,6 +161,11 @@ int surfh_cube_to_maps(surfh_plan *plan, const double *templates, int32_t n_temp
  * wavelength.  grad_norm receives r_l.r_l as [max_iter+1][Lc]; the loop stops when every plane is below the tolerance. */
 int surfh_cg_planes(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,
                     double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
+/* 3MG on the plane-wise model -- what `method = "qmm"` of the 2-D deconvolution driver selects
+ * (scripts/deconvolution_mrs_noRotation.py:199-212 -> criterion_2D.py:190-193 -> qmm.mmmg).  Scheme of surfh_mmmg with
+ * per-plane scalars; grad_norm receives |gradient_l| as [max_iter+1][Lc].                                            */
+int surfh_mmmg_planes(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,
+                      double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
 
 /* CG building blocks on device vectors, for the multi-GPU driver (one plan per rank,
  * RCCL all-reduce of `q` between surfh_normal_dev and surfh_cg_step_dev).            */

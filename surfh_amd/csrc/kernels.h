@@ -73,6 +73,11 @@ int launch_dot_planes(hipStream_t s, const float *a, const float *b, int nplanes
 int launch_cg_step_planes(hipStream_t s, float *x, float *r, const float *d, const float *q, int nplanes, long npix, const double *rr,
                           const double *dq, double *rrn, int update_r);
 int launch_cg_dir_planes(hipStream_t s, float *d, const float *r, int nplanes, long npix, const double *rrn, double *rr);
+// 3MG per plane: rr = r.r, mqm = m.Qm, d = r - (r.Qm / m.Qm) m ; then the 2x2 step in [d, m] with the carried images
+int launch_mmmg_dir_planes(hipStream_t s, float *d, const float *r, const float *m, const float *qm, int nplanes, long npix,
+                           double *rr, double *mqm);
+int launch_mmmg_step_planes(hipStream_t s, float *x, float *r, const float *d, float *m, float *qm, const float *qd, int nplanes,
+                            long npix, const double *mqm, int update_r);
 // (hth + diag(mu reg)) z = in per frequency bin (reg < 0 marks padding bins); *flag |= 1 on a non-positive pivot
 int launch_wct_solve(hipStream_t s, const float *hth, const float *reg, const double *mu, const float *in, float *out, int T,
                      long PL, int *flag);

@@ -520,6 +520,86 @@ __global__ __launch_bounds__(TPB) void cg_dir_planes_kernel(float *__restrict__ 
     if (threadIdx.x == 0) rr[blockIdx.x] = rrn[blockIdx.x];
 }
 
+// ---- 3MG on a batch of independent planes (the 2-D deconvolution drivers select it: deconvolution_mrs_noRotation.py:199-212).
+// Same two-step scheme as surfh_mmmg, every plane with its own scalars, one workgroup per plane.
+template <int N>
+__device__ inline void block_sum_bcast(double (&v)[N]) {   // sums over the workgroup, result in every thread
+    __shared__ double sm[N][TPB / 64];
+    __shared__ double tot[N];
+    __syncthreads();                                       // previous use of the buffers is over
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        double t = v[k];
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_down(t, o, 64);
+        if ((threadIdx.x & 63) == 0) sm[k][threadIdx.x >> 6] = t;
+    }
+    __syncthreads();
+    if (threadIdx.x < N) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += sm[threadIdx.x][w];
+        tot[threadIdx.x] = t;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = tot[k];
+}
+
+// rr = r.r (trace), mQm kept for the step; d = r + beta m with beta = -(r.Qm)/(m.Qm)
+__global__ __launch_bounds__(TPB) void mmmg_dir_planes_kernel(float *__restrict__ d, const float *__restrict__ r,
+                                                              const float *__restrict__ m, const float *__restrict__ qm, long npix,
+                                                              double *__restrict__ rr, double *__restrict__ mqm) {
+    const long off = (long)blockIdx.x * npix;
+    double v[3] = {0.0, 0.0, 0.0};
+    for (long i = threadIdx.x; i < npix; i += TPB) {
+        const double ri = r[off + i], qi = qm[off + i];
+        v[0] += ri * ri;
+        v[1] += ri * qi;
+        v[2] += (double)m[off + i] * qi;
+    }
+    block_sum_bcast<3>(v);
+    const float beta = v[2] > 0.0 ? (float)(-v[1] / v[2]) : 0.f;
+    for (long i = threadIdx.x; i < npix; i += TPB) d[off + i] = r[off + i] + beta * m[off + i];
+    if (threadIdx.x == 0) {
+        rr[blockIdx.x] = v[0];
+        mqm[blockIdx.x] = v[2];
+    }
+}
+
+// 2x2 subspace step of every plane in the basis [d, m]; a plane without curvature (no data, or converged) keeps still
+__global__ __launch_bounds__(TPB) void mmmg_step_planes_kernel(float *__restrict__ x, float *__restrict__ r, const float *__restrict__ d,
+                                                               float *__restrict__ m, float *__restrict__ qm,
+                                                               const float *__restrict__ qd, long npix,
+                                                               const double *__restrict__ mqm, int update_r) {
+    const long off = (long)blockIdx.x * npix;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};                    // d.Qd, d.Qm, d.r, m.r
+    for (long i = threadIdx.x; i < npix; i += TPB) {
+        const double di = d[off + i], ri = r[off + i];
+        v[0] += di * (double)qd[off + i];
+        v[1] += di * (double)qm[off + i];
+        v[2] += di * ri;
+        v[3] += (double)m[off + i] * ri;
+    }
+    block_sum_bcast<4>(v);
+    const double dQd = v[0], dQm = v[1], dr = v[2], mr = v[3], mQm = mqm[blockIdx.x];
+    double s0 = dQd > 0.0 ? dr / dQd : 0.0, s1 = 0.0;
+    if (dQd > 0.0 && mQm > 0.0) {
+        const double sc = sqrt(dQd * mQm), c = dQm / sc, det = 1.0 - c * c;
+        if (det > 1e-12) {
+            s0 = (dr / dQd - c * mr / sc) / det;
+            s1 = (mr / mQm - c * dr / sc) / det;
+        }
+    }
+    const float f0 = (float)s0, f1 = (float)s1;
+    for (long i = threadIdx.x; i < npix; i += TPB) {
+        const float mv = f0 * d[off + i] + f1 * m[off + i];
+        const float qv = f0 * qd[off + i] + f1 * qm[off + i];
+        x[off + i] += mv;
+        m[off + i] = mv;
+        qm[off + i] = qv;
+        if (update_r) r[off + i] -= qv;
+    }
+}
+
 inline int nblocks(long n, int cap = 2048) {
     long b = (n + TPB - 1) / TPB;
     if (b < 1) b = 1;
@@ -723,6 +803,18 @@ int launch_dot_planes(hipStream_t s, const float *a, const float *b, int nplanes
 int launch_cg_step_planes(hipStream_t s, float *x, float *r, const float *d, const float *q, int nplanes, long npix, const double *rr,
                           const double *dq, double *rrn, int update_r) {
     hipLaunchKernelGGL(cg_step_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, x, r, d, q, npix, rr, dq, rrn, update_r);
+    return (int)hipGetLastError();
+}
+
+int launch_mmmg_dir_planes(hipStream_t s, float *d, const float *r, const float *m, const float *qm, int nplanes, long npix,
+                           double *rr, double *mqm) {
+    hipLaunchKernelGGL(mmmg_dir_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, d, r, m, qm, npix, rr, mqm);
+    return (int)hipGetLastError();
+}
+
+int launch_mmmg_step_planes(hipStream_t s, float *x, float *r, const float *d, float *m, float *qm, const float *qd, int nplanes,
+                            long npix, const double *mqm, int update_r) {
+    hipLaunchKernelGGL(mmmg_step_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, x, r, d, m, qm, qd, npix, mqm, update_r);
     return (int)hipGetLastError();
 }
 

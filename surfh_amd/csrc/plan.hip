@@ -1605,6 +1605,70 @@ int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, con
     return done(0);
 }
 
+// ---- 3MG on independent planes: what `method = "qmm"` of the 2-D deconvolution driver runs
+// (scripts/deconvolution_mrs_noRotation.py:199-212 -> criterion_2D.py:190-193 -> qmm.mmmg); see surfh_mmmg for the scheme.
+int surfh_mmmg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+                      int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+    if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
+    if (p->T != 0) return fail("surfh_mmmg_planes is the solver of the plane-wise (no template) model; use surfh_mmmg with templates");
+    if (p->ch.empty()) return fail("plan has no channel");
+    HIP_OK(hipSetDevice(p->dev));
+    if (ensure_cg(p)) return 1;
+    if (!p->cg_qm && (dev_alloc(&p->cg_qm, (size_t)p->isize) || dev_alloc(&p->cg_dd, (size_t)p->isize))) return 1;
+    hipStream_t s = p->stream;
+    const int L = p->Lc;
+    const long npix = (long)p->Na * p->Nb, n = p->isize;
+    float *r = p->cg_r, *m = p->cg_d, *d = p->cg_dd, *qd = p->cg_q, *qm = p->cg_qm;
+    double *sc = nullptr;              // [2][L]: r.r, m.Qm
+    HIP_OK(hipMalloc((void **)&sc, (size_t)2 * L * sizeof(double)));
+    double *rr = sc, *mqm = sc + L;
+    auto done = [&](int rc) { hipFree(sc); return rc; };
+    auto Q = [&](const float *v, float *out) -> int {
+        if (normal_dev(p, v, out, mu)) return 1;
+        if (mu_reg != 0.0) LAUNCH_OK(launch_prior_add(s, v, out, L, p->Na, p->Nb, (float)mu_reg));
+        return 0;
+    };
+    if (hipMemcpyAsync(p->io_y, y, p->osize * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail("copy failed"));
+    if (adjoint_dev(p, p->io_y, p->cg_b, false)) return done(1);
+    int rc = 0;
+    if (mu != 1.0) rc = launch_scale(s, p->cg_b, n, (float)mu);
+    if (!rc) rc = x0 ? (int)hipMemcpyAsync(p->cg_x, x0, n * sizeof(float), hipMemcpyHostToDevice, s) : launch_fill_zero(s, p->cg_x, n);
+    if (!rc) rc = launch_fill_zero(s, m, n);
+    if (!rc) rc = launch_fill_zero(s, qm, n);
+    if (rc) return done(fail("3MG setup failed"));
+    if (Q(p->cg_x, qd)) return done(1);
+    rc = launch_residual(s, r, p->cg_b, qd, n);
+    if (rc) return done(fail("3MG setup failed"));
+    *nit = 0;
+    for (int it = 0;; ++it) {
+        rc = launch_mmmg_dir_planes(s, d, r, m, qm, L, npix, rr, mqm);
+        double *gn = grad_norm + (size_t)it * L;
+        if (!rc) rc = (int)hipMemcpyAsync(gn, rr, L * sizeof(double), hipMemcpyDeviceToHost, s);
+        if (!rc) rc = (int)hipStreamSynchronize(s);
+        if (rc) return done(fail("3MG iteration failed: %s", hipGetErrorString((hipError_t)rc)));
+        double worst = 0.0;
+        for (int l = 0; l < L; ++l) {
+            gn[l] = std::sqrt(gn[l]);
+            worst = std::max(worst, gn[l]);
+        }
+        if (it >= max_iter || worst < (double)npix * tol) break;
+        if (Q(d, qd)) return done(1);
+        const bool fresh = refresh > 0 && it % refresh == 0;
+        rc = launch_mmmg_step_planes(s, p->cg_x, r, d, m, qm, qd, L, npix, mqm, fresh ? 0 : 1);
+        if (rc) return done(fail("launch failed"));
+        if (fresh) {
+            if (Q(p->cg_x, qd)) return done(1);
+            rc = launch_residual(s, r, p->cg_b, qd, n);
+            if (rc) return done(fail("launch failed"));
+        }
+        *nit = it + 1;
+    }
+    rc = (int)hipMemcpyAsync(x, p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s);
+    if (!rc) rc = (int)hipStreamSynchronize(s);
+    if (rc) return done(fail("copy failed"));
+    return done(0);
+}
+
 // ---- drivers' LMM helpers on the device (spectroModel.py:187-198) -----------------------------
 static int lmm_host(surfh_plan *p, const double *templates, int32_t T, int32_t L, const float *in, float *out, bool to_cube) {
     if (!p || !templates || !in || !out) return fail("null argument");

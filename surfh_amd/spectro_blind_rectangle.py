@@ -176,6 +176,15 @@ class MRSBlurred(LinOp):
         """Device-resident linear CG on  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2)  (criterion_2D.py:60-250 with
         `qmm.lcg` restated).  Batched model: every plane is its own problem with its own step sizes; returns
         ``(x, grad_norm, nit)`` with ``grad_norm`` of shape ``[nit+1]`` (single image) or ``[nit+1, n_planes]``."""
+        return self._solve(self._L.surfh_cg_planes, data, mu, mu_reg, x0, max_iter, tol, refresh)
+
+    def mmmg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+        """Device-resident 3MG on the same criterion (`qmm.mmmg` restated for quadratic objectives) -- what the 2-D
+        deconvolution driver's ``method = "qmm"`` runs (scripts/deconvolution_mrs_noRotation.py:199-212).  Same returns as
+        ``cg`` except that ``grad_norm`` holds |grad| (not squared)."""
+        return self._solve(self._L.surfh_mmmg_planes, data, mu, mu_reg, x0, max_iter, tol, refresh)
+
+    def _solve(self, fn, data, mu, mu_reg, x0, max_iter, tol, refresh):
         y = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
         if y.size != self.osize:
             raise ValueError("data size mismatch")
@@ -185,15 +194,15 @@ class MRSBlurred(LinOp):
         x = np.empty(self.isize, dtype=np.float32)
         gn = np.zeros((max_iter + 1, self.n_planes), dtype=np.float64)
         nit = C.c_int32()
-        _lib.check(self._L.surfh_cg_planes(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
-                                           _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol), int(refresh),
-                                           _lib.fptr(x), _lib.dptr(gn), C.byref(nit)))
+        _lib.check(fn(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
+                      _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol), int(refresh),
+                      _lib.fptr(x), _lib.dptr(gn), C.byref(nit)))
         gn = gn[: nit.value + 1]
         return x.astype(np.float64).reshape(self.ishape), (gn if self.batched else gn[:, 0]).copy(), nit.value
 
 
 class QuadCriterion_MRS_2D:
-    """The reference's 2-D criterion (surfh/Simulation/criterion_2D.py:66-250): same constructor, ``run_method('lcg')``
+    """The reference's 2-D criterion (surfh/Simulation/criterion_2D.py:66-250): same constructor, ``run_method('lcg' | 'mmmg')``
     and ``get_crit_val``, on ``MRSBlurred`` (one image, or a stack of independent images solved together)."""
 
     def __init__(self, mu_spectro, y_spectro, model_spectro, mu_reg, printing=False, gradient="separated"):
@@ -207,8 +216,7 @@ class QuadCriterion_MRS_2D:
 
     def run_method(self, method="lcg", maximum_iterations=10, tolerance=1e-12, calc_crit=False, perf_crit=None, value_init=0.5):
         assert isinstance(self.mu_reg, (int, float))             # criterion_2D.py:115
-        if method != "lcg":
-            raise NotImplementedError("only method='lcg' is built (mmmg is out of the hot-path scope)")
+        solver = self.model_spectro.cg if method == "lcg" else self.model_spectro.mmmg       # criterion_2D.py:190-193
         if calc_crit or perf_crit is not None:
             raise NotImplementedError("per-iteration callbacks are built for the fusion criterion (QuadCriterion_MRS) only")
         init = np.ones(self.shape_of_output) * value_init if isinstance(value_init, (int, float)) else value_init
@@ -216,11 +224,12 @@ class QuadCriterion_MRS_2D:
         import time
         from .fusion import OptimizeResult
         t0 = time.time()
-        x, gn, nit = self.model_spectro.cg(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
-                                           max_iter=maximum_iterations, tol=tolerance)
+        x, gn, nit = solver(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
+                            max_iter=maximum_iterations, tol=tolerance)
         last = np.max(np.atleast_1d(gn[-1]))
+        last = np.sqrt(last) if method == "lcg" else last           # lcg traces r.r, mmmg |grad|
         res = OptimizeResult(x=x.ravel(), grad_norm=list(gn), nit=nit,
-                             success=bool(np.sqrt(last) < np.prod(self.shape_of_output[-2:]) * tolerance), time=time.time() - t0)
+                             success=bool(last < np.prod(self.shape_of_output[-2:]) * tolerance), time=time.time() - t0)
         if self.printing:
             print(f"Total time needed for {method} :", round(res.time, 3))
         return res
