@@ -23,6 +23,10 @@ struct GemmArgs {
     int splitK = 1;                // >1: K is cut in splitK slabs, slab s is written to C + s*sCsplit
     long sCsplit = 0;
     int accumulate = 0;            // 1: C += A*B (only with splitK==1)
+    // producer/consumer kernel only: operands already cut into their three bf16 pieces (launch_split3), piece q of
+    // element (m,k) at A3[q*pA3 + m*lda + k].  B3 alone (a constant operand split once) or both may be given.
+    const unsigned short *A3 = nullptr, *B3 = nullptr;
+    long pA3 = 0, pB3 = 0;
 };
 
 // returns hipError_t as int; name is used by the profiler
@@ -35,3 +39,6 @@ int launch_gemm_nt_bf16x3(hipStream_t stream, const GemmArgs &g);
 // The same product with a producer / consumer workgroup (8 waves, 128 x 256 tile, one workgroup per CU: gemm_pc3.hip).
 // N may be any multiple of 128.
 int launch_gemm_nt_bf16x3_pc(hipStream_t stream, const GemmArgs &g);
+
+// dst3[q*plane + i] = piece q (h, m, l) of src[i], the exact truncation split of gemm_bf16x3.hip; n multiple of 4
+int launch_split3(hipStream_t stream, const float *src, unsigned short *dst3, long n, long plane);

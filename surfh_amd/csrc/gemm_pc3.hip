@@ -23,6 +23,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -53,6 +54,9 @@ __device__ __forceinline__ void store_split(unsigned short *dst, float4 v) {
     *reinterpret_cast<uint2 *>(dst + 2 * PIECE) = make_uint2(pack2(l0, l1), pack2(l2, l3));
 }
 
+// PRE = 0: fp32 operands, split by the producers; 1: B given as bf16 pieces (constant operand, split once);
+// 2: both operands given as pieces -- the producers only move 16-byte chunks
+template <int PRE>
 __global__ __launch_bounds__(512, 1) void gemm_nt_bf16x3_pc_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,45 +76,84 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16x3_pc_kernel(GemmArgs g) {
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
         const int t = tid - 256;
-        const int r = t >> 3, c8 = t & 7;                         // row inside a 32-row pass, float4 index inside the 32 k
-        // full 128-byte lines: 8 consecutive lanes read the 32 k of one row, a wave instruction covers 8 whole rows
-        const float *Ab = g.A0 + (long)b * g.sA + kbeg + 4 * c8;
-        const float *Bb = g.B0 + (long)b * g.sB + kbeg + 4 * c8;
-        const float *src[NLD];
-        int lpos[NLD];
+        // fp32 rows: 32 per pass, 8 consecutive lanes read the 32 k of one row in whole 128-byte lines
+        constexpr int NF = PRE == 0 ? ROWS / 32 : PRE == 1 ? BM / 32 : 0;
+        // pre-split rows: 64 per pass, 4 consecutive lanes read the 64 bytes of one row of one piece
+        constexpr int SROW0 = PRE == 1 ? BM : 0, NSP = PRE == 0 ? 0 : (ROWS - SROW0) / 64, NS = 3 * NSP;
+        const int r = t >> 3, c8 = t & 7;
+        const int rs = t >> 2, c4 = t & 3;
+        const float *fsrc[NF > 0 ? NF : 1];
+        int fpos[NF > 0 ? NF : 1];
+        const unsigned short *ssrc[NS > 0 ? NS : 1];
+        int spos[NS > 0 ? NS : 1];
+        if constexpr (NF > 0) {
+            const float *Ab = g.A0 + (long)b * g.sA + kbeg + 4 * c8;
+            const float *Bb = g.B0 + (long)b * g.sB + kbeg + 4 * c8;
 #pragma unroll
-        for (int i = 0; i < NLD; ++i) {
-            const int row = r + 32 * i;                            // stage row: 0..127 A, 128..383 B
-            if (row < BM) {
-                src[i] = Ab + (long)(m0 + row) * g.lda;
-            } else {
-                int n = n0 + row - BM;
-                n = n < g.N ? n : g.N - 1;                         // ragged last tile: clamp, the columns are not stored
-                src[i] = Bb + (long)n * g.ldb;
+            for (int i = 0; i < NF; ++i) {
+                const int row = r + 32 * i;                            // stage row: 0..127 A, 128..383 B
+                if (row < BM) {
+                    fsrc[i] = Ab + (long)(m0 + row) * g.lda;
+                } else {
+                    int n = n0 + row - BM;
+                    n = n < g.N ? n : g.N - 1;                         // ragged last tile: clamp, the columns are not stored
+                    fsrc[i] = Bb + (long)n * g.ldb;
+                }
+                // LDS position (elements): row * 32 + (16-byte chunk ^ row bits 2..3) * 8 + (c8 & 1) * 4
+                fpos[i] = row * BK + (((c8 >> 1) ^ ((row >> 2) & 3)) * 8) + (c8 & 1) * 4;
             }
-            // LDS position (elements): row * 32 + (16-byte chunk ^ row bits 2..3) * 8 + (c8 & 1) * 4
-            lpos[i] = row * BK + (((c8 >> 1) ^ ((row >> 2) & 3)) * 8) + (c8 & 1) * 4;
         }
-        float4 cur[NLD], nxt[NLD];
-#define PC_LOAD(kt_, x_)                                                                \
-    {                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < NLD; ++i) x_[i] = *reinterpret_cast<const float4 *>(src[i] + (kt_) * BK); \
+        if constexpr (NS > 0) {
+#pragma unroll
+            for (int p = 0; p < NSP; ++p) {
+                const int row = SROW0 + rs + 64 * p;
+                const unsigned short *base;
+                long pl;
+                if (row < BM) {
+                    base = g.A3 + (long)b * g.sA + (long)(m0 + row) * g.lda + kbeg + 8 * c4;
+                    pl = g.pA3;
+                } else {
+                    int n = n0 + row - BM;
+                    n = n < g.N ? n : g.N - 1;
+                    base = g.B3 + (long)b * g.sB + (long)n * g.ldb + kbeg + 8 * c4;
+                    pl = g.pB3;
+                }
+#pragma unroll
+                for (int q = 0; q < 3; ++q) {
+                    ssrc[3 * p + q] = base + q * pl;
+                    spos[3 * p + q] = q * PIECE + row * BK + ((c4 ^ ((row >> 2) & 3)) * 8);
+                }
+            }
+        }
+        float4 fcur[NF > 0 ? NF : 1], fnxt[NF > 0 ? NF : 1];
+        u32x4 scur[NS > 0 ? NS : 1], snxt[NS > 0 ? NS : 1];
+#define PC_LOAD(kt_, f_, s_)                                                                                              \
+    {                                                                                                                     \
+        if constexpr (NF > 0) { _Pragma("unroll") for (int i = 0; i < NF; ++i) f_[i] = *reinterpret_cast<const float4 *>(fsrc[i] + (kt_) * BK); } \
+        if constexpr (NS > 0) { _Pragma("unroll") for (int i = 0; i < NS; ++i) s_[i] = *reinterpret_cast<const u32x4 *>(ssrc[i] + (kt_) * BK); }  \
     }
-#define PC_STORE(st_, x_)                                                               \
-    {                                                                                   \
-        unsigned short *base = lds + (st_) * STAGE;                                     \
-        _Pragma("unroll") for (int i = 0; i < NLD; ++i) store_split(base + lpos[i], x_[i]); \
+#define PC_STORE(st_, f_, s_)                                                                                             \
+    {                                                                                                                     \
+        unsigned short *base = lds + (st_) * STAGE;                                                                       \
+        if constexpr (NF > 0) { _Pragma("unroll") for (int i = 0; i < NF; ++i) store_split(base + fpos[i], f_[i]); }      \
+        if constexpr (NS > 0) { _Pragma("unroll") for (int i = 0; i < NS; ++i) *reinterpret_cast<u32x4 *>(base + spos[i]) = s_[i]; } \
     }
         // raw tiles are loaded two K steps ahead of the step the consumers work on (cur: kt+1, nxt: kt+2)
-        PC_LOAD(0, cur);
-        if (nk > 1) PC_LOAD(1, nxt);
-        PC_STORE(0, cur);
+        PC_LOAD(0, fcur, scur);
+        if (nk > 1) PC_LOAD(1, fnxt, snxt);
+        PC_STORE(0, fcur, scur);
         __syncthreads();
         for (int kt = 0; kt < nk; ++kt) {
+            if constexpr (NF > 0) {
 #pragma unroll
-            for (int i = 0; i < NLD; ++i) cur[i] = nxt[i];
-            if (kt + 2 < nk) PC_LOAD(kt + 2, nxt);
-            if (kt + 1 < nk) PC_STORE((kt + 1) & 1, cur);          // into the stage the consumers do not read
+                for (int i = 0; i < NF; ++i) fcur[i] = fnxt[i];
+            }
+            if constexpr (NS > 0) {
+#pragma unroll
+                for (int i = 0; i < NS; ++i) scur[i] = snxt[i];
+            }
+            if (kt + 2 < nk) PC_LOAD(kt + 2, fnxt, snxt);
+            if (kt + 1 < nk) PC_STORE((kt + 1) & 1, fcur, scur);   // into the stage the consumers do not read
             __syncthreads();
         }
 #undef PC_LOAD
@@ -183,18 +226,52 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_bf16x3_pc_kernel(GemmArgs g) {
 #undef PC_FLUSH
 }
 
+
+
+__global__ __launch_bounds__(256) void split3_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, long n4, long plane) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(src)[i];
+        unsigned h0, m0, l0, h1, m1, l1, h2, m2, l2, h3, m3, l3;
+        split3(v.x, h0, m0, l0);
+        split3(v.y, h1, m1, l1);
+        split3(v.z, h2, m2, l2);
+        split3(v.w, h3, m3, l3);
+        *reinterpret_cast<uint2 *>(dst + 4 * i) = make_uint2(pack2(h0, h1), pack2(h2, h3));
+        *reinterpret_cast<uint2 *>(dst + plane + 4 * i) = make_uint2(pack2(m0, m1), pack2(m2, m3));
+        *reinterpret_cast<uint2 *>(dst + 2 * plane + 4 * i) = make_uint2(pack2(l0, l1), pack2(l2, l3));
+    }
+}
+
 }  // namespace
+
+int launch_split3(hipStream_t stream, const float *src, unsigned short *dst3, long n, long plane) {
+    if (n % 4 || plane % 4) return (int)hipErrorInvalidValue;
+    const long n4 = n / 4;
+    long nb = (n4 + 255) / 256;
+    hipLaunchKernelGGL(split3_kernel, dim3((unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb))), dim3(256), 0, stream, src, dst3, n4, plane);
+    return (int)hipGetLastError();
+}
 
 // C[M][N] = A[M][K] * B[N][K]^T ; M multiple of 128, N of 128 (a ragged last 256-column tile is handled), K of 32*splitK.
 int launch_gemm_nt_bf16x3_pc(hipStream_t stream, const GemmArgs &g) {
     if (g.M % BM || g.N % 128 || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1 || g.accumulate || g.lda % 4 || g.ldb % 4)
         return (int)hipErrorInvalidValue;
-    static unsigned long long attr_done = 0;
-    if (int e = ensure_dynamic_lds(gemm_nt_bf16x3_pc_kernel, LDS_BYTES, attr_done)) return e;
+    if ((g.A3 && !g.B3) || (g.A3 && (g.pA3 % 8 || g.lda % 8)) || (g.B3 && (g.pB3 % 8 || g.ldb % 8))) return (int)hipErrorInvalidValue;
+    const int pre = g.A3 ? 2 : g.B3 ? 1 : 0;
     if ((double)(BM + 1) * (double)g.ldc * 4.0 >= 2147483648.0) return (int)hipErrorInvalidValue;
     const long total = (long)(g.M / BM) * ((g.N + BN - 1) / BN) * g.batch * g.splitK;
     dim3 grid((unsigned)(8 * ((total + 7) / 8)));
-    hipLaunchKernelGGL(gemm_nt_bf16x3_pc_kernel, grid, dim3(512), LDS_BYTES, stream, g);
+    static unsigned long long attr_done[3] = {0, 0, 0};
+    if (pre == 0) {
+        if (int e = ensure_dynamic_lds(gemm_nt_bf16x3_pc_kernel<0>, LDS_BYTES, attr_done[0])) return e;
+        hipLaunchKernelGGL(gemm_nt_bf16x3_pc_kernel<0>, grid, dim3(512), LDS_BYTES, stream, g);
+    } else if (pre == 1) {
+        if (int e = ensure_dynamic_lds(gemm_nt_bf16x3_pc_kernel<1>, LDS_BYTES, attr_done[1])) return e;
+        hipLaunchKernelGGL(gemm_nt_bf16x3_pc_kernel<1>, grid, dim3(512), LDS_BYTES, stream, g);
+    } else {
+        if (int e = ensure_dynamic_lds(gemm_nt_bf16x3_pc_kernel<2>, LDS_BYTES, attr_done[2])) return e;
+        hipLaunchKernelGGL(gemm_nt_bf16x3_pc_kernel<2>, grid, dim3(512), LDS_BYTES, stream, g);
+    }
     return (int)hipGetLastError();
 }
-

@@ -80,6 +80,7 @@ struct Channel {
     int K = 0, NP = 0, LdetP = 0, splitK = 1;
     long yoff = 0, ysize = 0;
     float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
+    unsigned short *W3 = nullptr, *Wt3 = nullptr;   // the two constant GEMM operands cut once into their bf16 pieces [3][rows][cols]
     DevEll fwd, adjT, adjRef;
     bool has_ref = false;
     bool bsum = false;   // no spectral blur: y[l][(p,s,a)] = sum over the slit's beta columns (MRSBlurred)
@@ -122,6 +123,7 @@ struct surfh_plan {
     int n_cu = 256;
     int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
     bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
+    bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
@@ -802,6 +804,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
                 LAUNCH_OK(launch_gemm_f32(sB, g));
             } else {
                 g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
+                g.B3 = c.W3; g.pB3 = (long)c.LdetP * c.K;
                 LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
@@ -851,6 +854,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
                 LAUNCH_OK(launch_gemm_f32(sB, g));
             } else {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
+                g.B3 = c.Wt3; g.pB3 = (long)c.LdetP * c.K;
                 LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
@@ -919,6 +923,8 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipFree(p->dscratch);
     for (auto &c : p->ch) {
         for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
+        hipFree(c.W3);
+        hipFree(c.Wt3);
         free_ell(&c.fwd);
         free_ell(&c.adjT);
         free_ell(&c.adjRef);
@@ -1063,6 +1069,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
+        const char *e9 = getenv("SURFH_WBLUR_PRESPLIT");
+        p->wblur_presplit = !(e9 && e9[0] == '0');   // 0: the producers split W again in every tile
         const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
         p->MPa = (ha + 127) / 128 * 128; p->KPa = (ha + 15) / 16 * 16;
         p->MPb = (hb + 127) / 128 * 128; p->KPb = (hb + 15) / 16 * 16;
@@ -1144,6 +1152,11 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         yoff += c.ysize;
         if (c.bsum) continue;
         c.splitK = pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu);
+        if (p->wblur_pc && !p->wblur_fp32 && p->wblur_presplit) {
+            const long nw = (long)c.LdetP * c.K;
+            if (dev_alloc(&c.W3, (size_t)3 * nw) || dev_alloc(&c.Wt3, (size_t)3 * nw)) return bail(1);
+            if (launch_split3(p->stream, c.W, c.W3, nw, nw) || launch_split3(p->stream, c.Wt, c.Wt3, nw, nw)) return bail(fail("operand split failed"));
+        }
         if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
         hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));
     }

@@ -321,8 +321,8 @@ def test_quad_criterion_mirror(c1):
     c_ref = orc.crit_val(om, y, ref["x"], 1.0, 5e3)
     c_init = orc.crit_val(om, y, np.ones(om.ishape) * 0.5, 1.0, 5e3)
     assert abs(c_gpu - c_ref) / c_ref < 1e-2 and c_gpu < c_init
-    with pytest.raises(NotImplementedError):
-        crit.run_method("mmmg")
+    res_m = crit.run_method("mmmg", maximum_iterations=8, value_init=0.5)       # the other solver (tests/test_gpu_driver.py)
+    assert res_m.nit == 8 and rel(res_m.x, res.x) < 1e-4
 
 
 @pytest.mark.parametrize("lmm", [True, False])
@@ -348,9 +348,10 @@ def test_disjoint_wavelength_windows(lmm):
 
 @pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_RX3": "0", "SURFH_FOLD2": "1"},
                                  {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
-                                 {"SURFH_WBLUR_PC": "0"}, {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_PACKED": "0"}],
+                                 {"SURFH_WBLUR_PC": "0"}, {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_PACKED": "0"},
+                                 {"SURFH_WBLUR_PRESPLIT": "0"}],
                          ids=["fold_fp32", "fold_fp32_two_launch", "dense_dft", "unfused_mix", "wblur_fp32", "wblur_4wave",
-                              "two_streams", "dft_two_pass_complex"])
+                              "two_streams", "dft_two_pass_complex", "wblur_split_in_kernel"])
 def test_alternative_kernel_paths(env):
     """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green."""
     cfg = problems.config1()

@@ -24,9 +24,17 @@ int run(int M, int N, int K, int sk, const char *name, bool check) {
     g.A0 = dA; g.lda = K; g.B0 = dB; g.ldb = K; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.splitK = sk; g.sCsplit = (long)M * N;
     hipStream_t st; CK(hipStreamCreate(&st));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int which = 0; which < 2; ++which) {
+    unsigned short *dA3, *dB3;
+    CK(hipMalloc(&dA3, A.size() * 6)); CK(hipMalloc(&dB3, B.size() * 6));
+    if (launch_split3(st, dA, dA3, (long)A.size(), (long)A.size()) || launch_split3(st, dB, dB3, (long)B.size(), (long)B.size())) { printf("split failed\n"); return 1; }
+    CK(hipStreamSynchronize(st));
+    const char *names[4] = {"shipped", "prod/cons", "pc B-pre", "pc AB-pre"};
+    for (int which = 0; which < 4; ++which) {
         if (which == 0 && N % 128) continue;
-        auto launch = [&]() { return which ? launch_gemm_nt_bf16x3_pc(st, g) : launch_gemm_nt_bf16x3(st, g); };
+        GemmArgs gg = g;
+        if (which >= 2) { gg.B3 = dB3; gg.pB3 = (long)B.size(); }
+        if (which == 3) { gg.A3 = dA3; gg.pA3 = (long)A.size(); }
+        auto launch = [&]() { return which ? launch_gemm_nt_bf16x3_pc(st, gg) : launch_gemm_nt_bf16x3(st, gg); };
         CK(hipMemset(dC, 0xFF, (size_t)nslab * M * N * 4));
         int rc = launch();
         if (rc) { printf("launch rc %d\n", rc); return 1; }
@@ -49,10 +57,10 @@ int run(int M, int N, int K, int sk, const char *name, bool check) {
         for (int i = 0; i < reps; ++i) launch();
         CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-        printf("%-8s %-9s M=%d N=%d K=%d sk=%d  rel L2 err %.3g   %.4f ms  %.1f TF/s fp32-equivalent\n", name, which ? "prod/cons" : "shipped", M, N, K, sk,
+        printf("%-8s %-9s M=%d N=%d K=%d sk=%d  rel L2 err %.3g   %.4f ms  %.1f TF/s fp32-equivalent\n", name, names[which], M, N, K, sk,
                check ? std::sqrt(num / den) : -1.0, ms, 2.0 * M * N * K / ms * 1e-9);
     }
-    hipFree(dA); hipFree(dB); hipFree(dC);
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dA3); hipFree(dB3);
     return 0;
 }
 
