@@ -135,6 +135,7 @@ struct surfh_plan {
     double *dscal = nullptr, *dscratch = nullptr;   // [8] device scalars, [1024] partial sums
     // profiling
     bool prof = false;
+    std::string prof_filter;                     // non-empty: only stages whose name starts with it are bracketed by events
     std::vector<ProfRec> pending;
     std::vector<hipEvent_t> pool;
     std::map<std::string, std::pair<long, double>> acc;
@@ -149,6 +150,7 @@ struct Prof {
     bool on;
     hipStream_t st;
     Prof(surfh_plan *pl, const char *name, hipStream_t stream = nullptr) : p(pl), on(pl->prof), st(stream ? stream : pl->stream) {
+        if (on && !pl->prof_filter.empty() && strncmp(name, pl->prof_filter.c_str(), pl->prof_filter.size()) != 0) on = false;
         if (!on) return;
         r.name = name;
         for (hipEvent_t *e : {&r.a, &r.b}) {
@@ -1719,6 +1721,11 @@ int surfh_cube_to_maps(surfh_plan *p, const double *templates, int32_t T, int32_
 int surfh_profile_enable(surfh_plan *p, int32_t on) {
     if (!p) return fail("null plan");
     p->prof = on != 0;
+    return 0;
+}
+int surfh_profile_filter(surfh_plan *p, const char *prefix) {
+    if (!p) return fail("null plan");
+    p->prof_filter = prefix ? prefix : "";
     return 0;
 }
 int32_t surfh_profile_count(surfh_plan *p) {

@@ -319,6 +319,10 @@ class spectroSigRLSCT(LinOp):
         return out
 
     # ---- instrumentation ---------------------------------------------------------------------
+    def profile_filter(self, prefix=None):
+        """Time only the stages whose name starts with ``prefix`` (None: all)."""
+        _lib.check(self._L.surfh_profile_filter(self._plan, prefix.encode() if prefix else None))
+
     def profile_enable(self, on=True):
         _lib.check(self._L.surfh_profile_enable(self._plan, 1 if on else 0))
 
