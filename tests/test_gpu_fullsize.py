@@ -81,6 +81,46 @@ def test_config2_forward_parity_full_size(c2):
     assert e < 1e-5
 
 
+def test_config2_solvers_agree_and_projections(c2):
+    """Full size, size-independent properties: 3MG and CG produce the same iterates on the quadratic criterion; the
+    slice -> cube view of the data fills exactly the planes where a detector sample's spectral response peaks and agrees
+    with the float64 restatement; the real-data projections are exact on a constant cube away from the FoV edge."""
+    cfg, m = c2
+    y = m.forward(cfg["maps"])
+    x0 = np.full(m.ishape, 0.5)
+    xc, gc, _ = m.cg(y, mu=1.0, mu_reg=5e3, x0=x0, max_iter=6)
+    xm, gm, _ = m.mmmg(y, mu=1.0, mu_reg=5e3, x0=x0, max_iter=6)
+    dev = float(np.max(np.abs(gm ** 2 - gc) / gc))
+    print(f"config2 3MG vs CG after 6 iterations: x {rel(xm, xc):.2e}, grad norm {dev:.2e}", flush=True)
+    assert rel(xm, xc) < 1e-4 and dev < 1e-3 and gm[-1] < gm[0]
+    ch = m.channels[0]
+    t = time.time()
+    cube = ch.sliceToCube(y)
+    tab = orc.build_channel(cfg["specs"][0], cfg["alpha_axis"], cfg["beta_axis"], cfg["wavel"], cfg["step_deg"],
+                            cfg["pointings"][0], with_grid=False)
+    peaks = np.unique(np.argmax(tab.wpsf_dirac, axis=1)) + tab.wslice[0]
+    filled = np.flatnonzero(np.abs(cube).sum(axis=(1, 2)) > 0)
+    assert cube.shape == (cfg["Lc"], 251, 251) and np.array_equal(filled, peaks)       # index path: exact
+    ref = orc.slice_to_cube(tab, y, cfg["alpha_axis"], cfg["beta_axis"], cfg["Lc"])
+    e = rel(cube, ref)
+    print(f"config2 sliceToCube rel err {e:.2e}, {len(peaks)} filled planes ({time.time() - t:.1f}s)", flush=True)
+    assert e < 1e-5
+    # constant cube -> every slit sample is the sum of its slit's edge weights; sent back, the box kernel and the
+    # interpolation reproduce srf inside the FoV
+    L = ch.oshape[2]
+    sl = ch.realData_cubeToSlice(np.ones((L, 251, 251)))
+    w = np.array([ch.slicer.get_slit_weights(s, ch.slicer.get_slit_slices(s))[0, 0].sum() for s in range(ch.oshape[1])])
+    assert sl.shape == (ch.oshape[1], L, ch.oshape[3]) and np.allclose(sl, w[:, None, None], rtol=2e-6)
+    tab0 = orc.build_channel(cfg["specs"][0], cfg["alpha_axis"], cfg["beta_axis"], cfg["wavel"], cfg["step_deg"], [(0.0, 0.0)])
+    rng = np.random.default_rng(3)
+    s_in = rng.random(sl.shape)
+    back = ch.realData_sliceToCube(s_in, (L, 251, 251))
+    sel = [0, L // 2, L - 1]
+    ref_b = orc.realdata_slice_to_cube(tab0, s_in[:, sel], (3, 251, 251), cfg["alpha_axis"], cfg["beta_axis"])
+    assert rel(back[sel], ref_b) < 1e-5
+    ch.close()
+
+
 @pytest.mark.parametrize("N,Lc", [(300, 96), (501, 64)], ids=["even_300", "driver_default_501"])
 def test_other_image_sizes(N, Lc):
     """Image sizes other than the benchmark's 251: an even size with two row tiles per DFT pass (N/2+1 = 151 > 128) and
