@@ -8,7 +8,7 @@
  *   jax_utils.{lmm_*, dft, idft, dft_mult, wblur_subSampling, wblur_t}
  *                                          (surfh/ToolsDir/jax_utils.py:10-91)
  *   cythons_files.solve_2D_hypercube       (surfh/ToolsDir/cythons_files.pyx:163-193)
- *   NpDiff_r / NpDiff_c + qmm.lcg loop     (surfh/Simulation/fusion_CT.py:16-43,194-225)
+ *   NpDiff_r / NpDiff_c + qmm.lcg / qmm.mmmg loops (surfh/Simulation/fusion_CT.py:16-43,194-225)
  * All file:line citations are relative to the reference tree (sidiso/surfh @ 2025-02-04).
  *
  * Conventions
@@ -17,8 +17,13 @@
  *     available from surfh_last_error() (thread-local, valid until the next call).
  *   - the geometry tables are produced by the host side (surfh_amd/geometry.py),
  *     which restates instru.py / slicer.py; the library only consumes them.
- *   - arithmetic type: fp32 on device (fp32-input MFMA, exact fp32 products);
- *     inner products of the CG loop accumulate in fp64.
+ *   - arithmetic type: fp32 on device.  The dense stages (spectral blur, DFT passes) evaluate every fp32
+ *     product exactly as six bf16 matrix-core products of a three-way operand split, accumulated in fp32
+ *     (fp32-input MFMA kernels behind SURFH_* environment switches); inner products of the solvers accumulate
+ *     in fp64.
+ *   - environment switches read at plan creation (A/B paths, all parity-tested): SURFH_DFT_RX3=0,
+ *     SURFH_FOLD2=1, SURFH_DFT_DENSE=1, SURFH_NO_FUSED_MIX=1, SURFH_DFT_PACKED=0, SURFH_WBLUR_FP32=1,
+ *     SURFH_WBLUR_PC=0, SURFH_WBLUR_PRESPLIT=0, SURFH_OVERLAP=1.
  */
 #ifndef SURFH_AMD_H
 #define SURFH_AMD_H
