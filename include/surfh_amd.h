@@ -75,7 +75,7 @@ typedef struct {
 typedef struct {
     int32_t n_alpha, n_beta;           /* cube spatial shape                                        */
     int32_t n_lambda;                  /* cube planes Lc                                            */
-    int32_t n_templates;               /* T; 0 => no LMM (input is the cube itself)                 */
+    int32_t n_templates;               /* T <= 8; 0 => no LMM (input is the cube itself)            */
     const double *templates;           /* [T][Lc] or NULL                                           */
     const double *sotf;                /* [Lc][n_alpha][n_beta/2+1] complex128 interleaved (re,im);
                                           NULL (only with n_templates = 0): no spatial blur, H = 1  */

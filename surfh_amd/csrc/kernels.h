@@ -1,5 +1,7 @@
 // Device kernels of the surfh hot path other than the dense GEMM (see gemm_f32.h).
 #pragma once
+// templates (abundance maps) the spectral-mix kernels hold in registers per frequency bin
+constexpr int SURFH_MAX_TEMPLATES = 8;
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 

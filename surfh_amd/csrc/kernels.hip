@@ -39,7 +39,7 @@ __global__ __launch_bounds__(TPB) void specmix_fwd_kernel(const float *__restric
     *reinterpret_cast<float4 *>(spec + (PL + k) * LP + l4) = xi;
 }
 
-constexpr int MAXT = 8;
+constexpr int MAXT = SURFH_MAX_TEMPLATES;
 
 // one workgroup per frequency bin k: madj[t][c][k] = sum_l tpl[t][l] (conj(H) Y)[c][k][l]
 __global__ __launch_bounds__(TPB) void specmix_adj_kernel(const float *__restrict__ spec,

@@ -951,6 +951,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     if (cfg->n_channels == 0 && cfg->n_templates < 1) return fail("a plan without channels needs templates (Model_WCT)");
     if (!cfg->sotf && cfg->n_templates > 0) return fail("sotf is NULL");      // NULL = no spatial blur, plane-wise plans only
     if (cfg->n_templates > 0 && !cfg->templates) return fail("templates is NULL");
+    if (cfg->n_templates > SURFH_MAX_TEMPLATES)
+        return fail("n_templates = %d: at most %d templates are supported", cfg->n_templates, SURFH_MAX_TEMPLATES);
     int ndev = 0;
     HIP_OK(hipGetDeviceCount(&ndev));
     if (cfg->device < 0 || cfg->device >= ndev) return fail("device %d not available (%d devices): the HIP path has no CPU fallback", cfg->device, ndev);

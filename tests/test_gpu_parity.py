@@ -325,6 +325,33 @@ def test_quad_criterion_mirror(c1):
     assert res_m.nit == 8 and rel(res_m.x, res.x) < 1e-4
 
 
+def test_error_behaviour():
+    """Failures are loud and carry a message: the reference's own (field of view outside the cube -> ValueError,
+    cython_2D_interpolation.py:472-478; wrong input size) and the library's limits."""
+    import copy
+    cfg = problems.config1()
+    m = build_model(cfg)
+    with pytest.raises(ValueError, match="expected"):
+        m.forward(np.zeros((3, 64, 64)))
+    with pytest.raises(ValueError, match="size"):
+        m.cg(np.zeros(7), max_iter=1)
+    m.close()
+    far = copy.deepcopy(cfg)
+    far["pointings"] = [[(a + 40 * problems.STEP_DEG, b) for a, b in far["pointings"][0]]]
+    with pytest.raises(ValueError, match="out of bounds"):
+        build_model(far)
+    many = dict(cfg)
+    many["templates"] = np.ones((9, cfg["templates"].shape[1]))
+    with pytest.raises(ValueError, match="at most 8 templates"):
+        build_model(many)
+    bad = dict(cfg)
+    bad["sotf"] = cfg["sotf"][:, :, :-1]
+    with pytest.raises(ValueError, match="sotf shape"):
+        build_model(bad)
+    with pytest.raises(ValueError, match="without templates"):
+        build_model(dict(cfg, sotf=None))
+
+
 @pytest.mark.parametrize("lmm", [True, False])
 def test_disjoint_wavelength_windows(lmm):
     """A plan stores only the union of its channels' windows; here that union has a gap."""
