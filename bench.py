@@ -163,6 +163,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
 
+    # parity gate reported with the number: the dot test of this rank's operator at benchmark size, inner
+    # products accumulated in float64, non-negative test vectors (the physical regime; gate < 1e-6).  Outside the timed region.
+    gate = None
+    if rank == 0:
+        rng = np.random.default_rng(5)
+        v, u = rng.random(m.isize), rng.random(m.osize)
+        lhs = float(np.vdot(np.asarray(m.rmatvec(u), dtype=np.float64), v))
+        rhs = float(np.vdot(u, np.asarray(m.matvec(v), dtype=np.float64)))
+        gate = {"dot_test_gap": abs(lhs - rhs) / abs(rhs), "gate": 1e-6,
+                "note": "|<A^T u, v> - <u, A v>| / |<u, A v>| of the operator this rank holds, at benchmark size; the <=1e-5 "
+                        "forward / adjoint gates against the float64 oracle and the bit-exact index tables are tests/ (pytest -m gpu)"}
+        log(f"[parity gate] dot-test gap {gate['dot_test_gap']:.2e}")
+
     if rank == 0:
         for name, (cnt, ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
             log(f"[prof warm-up] {name:28s} launches {cnt:5d}  avg {ms / max(cnt, 1):8.4f} ms  per-step {ms / n_all:8.4f} ms")
@@ -240,7 +253,7 @@ def main():
                                     "config2: band 2A, 251x251x1024 cube, 4-point dither, T=4, mu_reg=5e3"),
                        "parallelism": f"{world} rank(s), (band,pointings) units {fus.assignment}",
                        "osize_rank0": int(m.osize), "grad_norm_first_last": [fus.grad_norm[0], fus.grad_norm[-1]]},
-            "roofline": roof, "stage_ms_per_step": stage_ms,
+            "roofline": roof, "parity_gates": gate, "stage_ms_per_step": stage_ms,
             "stage_ms_note": f"per-stage HIP-event times from the {n_all} untimed warm-up step(s) with every stage bracketed; "
                              "the timed region brackets only the kernel group of `roofline`",
         }
