@@ -190,7 +190,9 @@ def main():
             if name.startswith("gemm_wblur"):
                 if os.environ.get("SURFH_WBLUR_FP32") == "1":
                     return "gemm_f32_kernel<128, 128>"
-                return "gemm_nt_bf16x3_pc_kernel" if os.environ.get("SURFH_WBLUR_PC") != "0" else "gemm_nt_bf16x3_kernel"
+                if os.environ.get("SURFH_WBLUR_PC") == "0":
+                    return "gemm_nt_bf16x3_kernel"
+                return "gemm_nt_f16x2_pc_kernel" if os.environ.get("SURFH_WBLUR_F16") != "0" else "gemm_nt_bf16x3_pc_kernel"
             if name.startswith("dft_rx3_"):
                 return "dft_rx3_kernel"            # four template instances <KIND, MIX> of one kernel (dft_rx3.hip)
             if name.startswith("dft_fold_cols"):
@@ -226,13 +228,17 @@ def main():
                 flops_step = sum(2.0 * 2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
                                  for c in m.channels)
                 ach = flops_step / per_step / avg_s / 1e12
+                nprod = 3.0 if dom.startswith("gemm_nt_f16x2") else 6.0 if dom.startswith("gemm_nt_bf16x3") else None
                 roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                         "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "kernel": dom, "launches": cnt,
                         "avg_ms": ms / cnt,
                         "note": "algorithmic fp32 flops of R/R^T priced against the fp32-input MFMA peak (the dtype the path "
-                                "computes in); the kernel evaluates each fp32 product as 6 bf16 MFMA products (exact 3-way "
-                                "split), i.e. it sustains 6x this rate on the bf16 matrix cores",
-                        "bf16_matrix_core_tflops": 6.0 * ach, "bf16_peak_frac": 6.0 * ach / 2500.0}
+                                "computes in).  The kernel evaluates each fp32 product as 3 fp16 matrix-core products of a "
+                                "two-piece round-to-nearest operand split (6 bf16 products of a three-piece split with "
+                                "SURFH_WBLUR_F16=0), i.e. it sustains that multiple of this rate on the 16-bit matrix cores"}
+                if nprod:
+                    roof["matrix_core_16bit_tflops"] = nprod * ach
+                    roof["matrix_core_16bit_peak_frac"] = nprod * ach / 2500.0
             else:
                 # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
                 # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel

@@ -27,6 +27,12 @@ struct GemmArgs {
     // element (m,k) at A3[q*pA3 + m*lda + k].  B3 alone (a constant operand split once) or both may be given.
     const unsigned short *A3 = nullptr, *B3 = nullptr;
     long pA3 = 0, pB3 = 0;
+    // two-piece fp16 kernel (gemm_pc16.hip): B as its fp16 pieces B16[q*pB16 + n*ldb + k] of B / sB16; the scale of A
+    // derived on the device from the 64 max slots `amax` its producer filled, or fixed (sA16) when amax is NULL
+    const unsigned short *B16 = nullptr;
+    long pB16 = 0;
+    float sB16 = 0.f, sA16 = 0.f;
+    const unsigned *amax = nullptr;
 };
 
 // returns hipError_t as int; name is used by the profiler
@@ -42,3 +48,9 @@ int launch_gemm_nt_bf16x3_pc(hipStream_t stream, const GemmArgs &g);
 
 // dst3[q*plane + i] = piece q (h, m, l) of src[i], the exact truncation split of gemm_bf16x3.hip; n multiple of 4
 int launch_split3(hipStream_t stream, const float *src, unsigned short *dst3, long n, long plane);
+
+// Two-piece fp16 form of the producer/consumer GEMM (half the matrix-core work of the bf16 split, see gemm_pc16.hip)
+int launch_gemm_nt_f16x2_pc(hipStream_t stream, const GemmArgs &g);
+// dst2[q*plane + i] = fp16 piece q (h, l) of src[i] / scale (round to nearest); scale from gemm_f16x2_scale(max |src|)
+int launch_split2h(hipStream_t stream, const float *src, unsigned short *dst2, long n, long plane, float scale);
+float gemm_f16x2_scale(float amax);

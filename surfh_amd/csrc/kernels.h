@@ -34,7 +34,13 @@ struct EllTable {
     const float *val = nullptr;    // [R][W]
     const int64_t *dst_off = nullptr;  // [R]
 };
-int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate);
+// pmax / slots (optional, gather mode only): every wave stores max |output| (bit pattern) in its entry of pmax
+// [spmm_rows_waves()], a one-workgroup pass then leaves the overall maximum in slots[0..63] -- the scale of the data
+// operand of the two-piece fp16 GEMM (gemm_pc16.hip)
+int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate,
+                     unsigned *pmax = nullptr, unsigned *slots = nullptr);
+long spmm_rows_waves(const EllTable &t, int nlam);
+long ymat_from_y_waves(int PS, int Ldet, int aout);
 
 // [L][Na][Nb] (wavelength-major, the reference's cube layout) <-> [NBP][NAP][LP] (wavelength innermost)
 int launch_cube_to_lam_inner(hipStream_t s, const float *src, float *dst, int l0, int L, int na, int nb, int nap, int LP);
@@ -47,7 +53,8 @@ int launch_unpad_planes(hipStream_t s, const float *src, float *dst, int B, int 
 int launch_y_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit, float *y, int PS, int Ldet,
                         int aout, int LdetP);
 // ymat[(ps*aout + a)*LdetP + l] = y[(ps*Ldet + l)*aout + a]
-int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP);
+int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP, unsigned *pmax = nullptr,
+                       unsigned *slots = nullptr);
 int launch_fill_zero(hipStream_t s, float *p, long n);
 
 // ---- CG vector kernels (qmm.lcg loop body; fusion_CT.py:16-43 priors) --------------------------

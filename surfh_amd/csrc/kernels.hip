@@ -243,41 +243,71 @@ __global__ __launch_bounds__(TPB) void wct_solve_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------
 // sparse row gather vectorised over wavelength: one workgroup = one table row x 1024 wavelengths
 // ---------------------------------------------------------------------------------------------
+// max over the wave of a non-negative value, then one atomicMax per wave into one of 64 slots
+// max |value| of a kernel's output for the two-piece fp16 GEMM's operand scale: every wave stores its maximum (bit pattern
+// of a non-negative float) in its own entry of `pmax`, one small workgroup reduces the entries afterwards.  (atomicMax
+// into 64 shared slots serialised in L2 at about 140 ns each and made the gather 3.5x slower; reading the slot first and
+// issuing the atomic only when it raises the value still cost 45 %, because the first wavefront of waves all see zero.)
+__device__ __forceinline__ void wave_amax_store(float m, unsigned *pmax, unsigned wave_id) {
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0) pmax[wave_id] = __float_as_uint(m);
+}
+
+// 64 workgroups, one slot each (the GEMM takes the maximum over the 64 slots)
+__global__ __launch_bounds__(1024) void amax_reduce_kernel(const unsigned *__restrict__ pmax, long n, unsigned *__restrict__ slots) {
+    unsigned m = 0;
+    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n; i += (long)gridDim.x * 1024) m = max(m, pmax[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    __shared__ unsigned sm[16];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        unsigned v = threadIdx.x < 16 ? sm[threadIdx.x] : 0u;
+        for (int o = 8; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
+        if (threadIdx.x == 0) slots[blockIdx.x] = v;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float *__restrict__ src,
-                                                        float *__restrict__ dst, int nlam, int accumulate) {
+                                                        float *__restrict__ dst, int nlam, int accumulate, unsigned *amax) {
     // workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD one
     // contiguous band of table rows, so neighbouring rows -- which share most of their taps -- hit the same L2
     const int per = (t.R + 7) / 8;
     const int r = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     const int l4 = (blockIdx.y * TPB + threadIdx.x) * 4;
-    if (r >= t.R || l4 >= nlam) return;
-    const int n = t.cnt[r];
-    const int64_t *col = t.col + (long)r * t.W;
-    const float *val = t.val + (long)r * t.W;
+    if (r >= t.R) return;                                 // workgroup-uniform
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    int e = 0;
-    for (; e + 4 <= n; e += 4) {
-        const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
-        const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
-        const float4 x2 = *reinterpret_cast<const float4 *>(src + col[e + 2] + l4);
-        const float4 x3 = *reinterpret_cast<const float4 *>(src + col[e + 3] + l4);
-        const float v0 = val[e], v1 = val[e + 1], v2 = val[e + 2], v3 = val[e + 3];
-        acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
-        acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
-        acc.x += v2 * x2.x; acc.y += v2 * x2.y; acc.z += v2 * x2.z; acc.w += v2 * x2.w;
-        acc.x += v3 * x3.x; acc.y += v3 * x3.y; acc.z += v3 * x3.z; acc.w += v3 * x3.w;
+    if (l4 < nlam) {
+        const int n = t.cnt[r];
+        const int64_t *col = t.col + (long)r * t.W;
+        const float *val = t.val + (long)r * t.W;
+        int e = 0;
+        for (; e + 4 <= n; e += 4) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+            const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
+            const float4 x2 = *reinterpret_cast<const float4 *>(src + col[e + 2] + l4);
+            const float4 x3 = *reinterpret_cast<const float4 *>(src + col[e + 3] + l4);
+            const float v0 = val[e], v1 = val[e + 1], v2 = val[e + 2], v3 = val[e + 3];
+            acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+            acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
+            acc.x += v2 * x2.x; acc.y += v2 * x2.y; acc.z += v2 * x2.z; acc.w += v2 * x2.w;
+            acc.x += v3 * x3.x; acc.y += v3 * x3.y; acc.z += v3 * x3.z; acc.w += v3 * x3.w;
+        }
+        for (; e < n; ++e) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+            const float v0 = val[e];
+            acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+        }
+        float4 *p = reinterpret_cast<float4 *>(dst + t.dst_off[r] + l4);
+        if (accumulate) {
+            const float4 o = *p;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        *p = acc;
     }
-    for (; e < n; ++e) {
-        const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
-        const float v0 = val[e];
-        acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
-    }
-    float4 *p = reinterpret_cast<float4 *>(dst + t.dst_off[r] + l4);
-    if (accumulate) {
-        const float4 o = *p;
-        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
-    }
-    *p = acc;
+    if (amax)       // lanes beyond the window carry 0; the whole wave takes part in the reduction
+        wave_amax_store(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))), amax,
+                        (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
 // [L][na][nb] planes l0.. of a wavelength-major cube -> [nb][nap][LP] wavelength innermost (32x32 LDS tile transpose)
@@ -354,12 +384,16 @@ __global__ __launch_bounds__(TPB) void y_from_cpart_kernel(const float *__restri
 }
 
 __global__ __launch_bounds__(TPB) void ymat_from_y_kernel(const float *__restrict__ y, float *__restrict__ ymat, int PS,
-                                                          int Ldet, int aout, int LdetP) {
+                                                          int Ldet, int aout, int LdetP, unsigned *amax) {
     const int l = blockIdx.x * TPB + threadIdx.x;
     const int n = blockIdx.y;
-    if (l >= Ldet) return;
-    const int ps = n / aout, a = n % aout;
-    ymat[(long)n * LdetP + l] = y[((long)ps * Ldet + l) * aout + a];
+    float v = 0.f;
+    if (l < Ldet) {
+        const int ps = n / aout, a = n % aout;
+        v = y[((long)ps * Ldet + l) * aout + a];
+        ymat[(long)n * LdetP + l] = v;
+    }
+    if (amax) wave_amax_store(fabsf(v), amax, (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
 __global__ __launch_bounds__(TPB) void fill_zero_kernel(float *p, long n) {
@@ -683,11 +717,18 @@ __global__ __launch_bounds__(TPB) void lmm_cube2maps_kernel(const float *__restr
 
 }  // namespace
 
-int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate) {
+long spmm_rows_waves(const EllTable &t, int nlam) {
+    return (long)((t.R + 7) / 8 * 8) * ((nlam / 4 + TPB - 1) / TPB) * (TPB / 64);
+}
+long ymat_from_y_waves(int PS, int Ldet, int aout) { return (long)((Ldet + TPB - 1) / TPB) * PS * aout * (TPB / 64); }
+
+int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate, unsigned *pmax,
+                     unsigned *slots) {
     if (t.R == 0 || nlam <= 0) return 0;
-    if (nlam % 4) return (int)hipErrorInvalidValue;
+    if (nlam % 4 || (pmax && (accumulate || !slots))) return (int)hipErrorInvalidValue;
     dim3 grid((t.R + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate);
+    hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate, pmax);
+    if (pmax) hipLaunchKernelGGL(amax_reduce_kernel, dim3(64), dim3(1024), 0, s, pmax, spmm_rows_waves(t, nlam), slots);
     return (int)hipGetLastError();
 }
 
@@ -723,9 +764,12 @@ int launch_y_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit
     return (int)hipGetLastError();
 }
 
-int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP) {
+int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP, unsigned *pmax,
+                       unsigned *slots) {
+    if (pmax && !slots) return (int)hipErrorInvalidValue;
     dim3 grid((Ldet + TPB - 1) / TPB, PS * aout);
-    hipLaunchKernelGGL(ymat_from_y_kernel, grid, dim3(TPB), 0, s, y, ymat, PS, Ldet, aout, LdetP);
+    hipLaunchKernelGGL(ymat_from_y_kernel, grid, dim3(TPB), 0, s, y, ymat, PS, Ldet, aout, LdetP, pmax);
+    if (pmax) hipLaunchKernelGGL(amax_reduce_kernel, dim3(64), dim3(1024), 0, s, pmax, ymat_from_y_waves(PS, Ldet, aout), slots);
     return (int)hipGetLastError();
 }
 

@@ -81,6 +81,11 @@ struct Channel {
     long yoff = 0, ysize = 0;
     float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
     unsigned short *W3 = nullptr, *Wt3 = nullptr;   // the two constant GEMM operands cut once into their bf16 pieces [3][rows][cols]
+    unsigned short *W16 = nullptr, *Wt16 = nullptr; // ... or into their two fp16 pieces [2][rows][cols] of W / sW (gemm_pc16.hip)
+    float sW = 1.f;
+    unsigned *amax = nullptr;                       // [2][64] max slots of the data operands: Xs (forward), ymat (adjoint)
+    unsigned *pmax = nullptr;                       // per-wave maxima of the kernel that wrote the operand (reduced into amax)
+    long pmax_adj = 0;
     DevEll fwd, adjT, adjRef;
     bool has_ref = false;
     bool bsum = false;   // no spectral blur: y[l][(p,s,a)] = sum over the slit's beta columns (MRSBlurred)
@@ -124,6 +129,7 @@ struct surfh_plan {
     int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
     bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
     bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
+    bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
@@ -415,6 +421,9 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                     W[(size_t)l * c->K + k] = v;
                     Wt[k * c->LdetP + l] = v;
                 }
+        float wmax = 0.f;
+        for (float v : W) wmax = std::max(wmax, std::fabs(v));
+        c->sW = gemm_f16x2_scale(wmax);
         if (dev_upload(&c->W, W) || dev_upload(&c->Wt, Wt)) return 1;
     }
     if (dev_alloc(&c->Xs, (size_t)c->NP * c->K)) return 1;
@@ -426,18 +435,20 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     return 0;
 }
 
-int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu) {
+int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu, int max_steps = 34) {
     if (forced > 0) return (c.K % (32 * forced) == 0) ? forced : 1;
     if (pc_kernel) {
         // producer/consumer kernel (128 x 256 tiles, one workgroup per CU).  The slab length is set by accuracy first:
         // accumulation chains of the split-bf16 products stay unbiased up to about 1024 k (gemm_pc3.hip header), so
         // take the fewest slabs with K / s <= 1088; among slab counts up to 1.5x that, the one that fills the last
-        // round of workgroups best.
+        // round of workgroups best.  The two-piece fp16 products have no small terms to lose: measured bias on non-negative
+        // operands -1.3e-7 for one 4096-long chain (plain fp32 accumulation), so they run chains of up to 4352 k
+        // (max_steps 136): a quarter of the slabs to sum.
         const long tiles = (long)(c.NP / 128) * ((c.LdetP + 255) / 256);
         const int steps = c.K / 32;
         int smin = 0;
         for (int s = 1; s <= steps; ++s)
-            if (steps % s == 0 && steps / s <= 34) { smin = s; break; }
+            if (steps % s == 0 && steps / s <= max_steps) { smin = s; break; }
         if (!smin) return 1;
         int best = smin;
         double best_t = -1.0;
@@ -785,9 +796,10 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
     // gather on the main stream, spectral-blur GEMM + slab sum on the second one: GEMM(c) overlaps gather(c+1)
     hipStream_t sB = (p->overlap && p->stream2) ? p->stream2 : s;
     for (auto &c : p->ch) {
+        const bool f16 = c.W16 != nullptr;
         {
             Prof pr(p, "spmm_gather_fwd");
-            LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0));
+            LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, f16 ? c.amax : nullptr));
         }
         if (c.bsum) {   // y[l][(p,s,a)] = Xs[(p,s,a)][l]
             Prof pr(p, "y_transpose");
@@ -807,7 +819,8 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             } else {
                 g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
                 g.B3 = c.W3; g.pB3 = (long)c.LdetP * c.K;
-                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
+                g.B16 = c.W16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
+                LAUNCH_OK(f16 ? launch_gemm_nt_f16x2_pc(sB, g) : p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
         {
@@ -841,9 +854,11 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
             continue;
         }
+        const bool f16 = c.W16 != nullptr;
         {
             Prof pr(p, "ymat_from_y", sB);
-            LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP));
+            LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax + c.pmax_adj : nullptr,
+                                         f16 ? c.amax + 64 : nullptr));
         }
         GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
         g.A0 = c.ymat; g.lda = c.LdetP;
@@ -857,7 +872,8 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             } else {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
                 g.B3 = c.Wt3; g.pB3 = (long)c.LdetP * c.K;
-                LAUNCH_OK(p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
+                g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax + 64;
+                LAUNCH_OK(f16 ? launch_gemm_nt_f16x2_pc(sB, g) : p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
         if (chain(p, sB, s)) return 1;
@@ -927,6 +943,10 @@ int surfh_plan_destroy(surfh_plan *p) {
         for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
         hipFree(c.W3);
         hipFree(c.Wt3);
+        hipFree(c.W16);
+        hipFree(c.Wt16);
+        hipFree(c.amax);
+        hipFree(c.pmax);
         free_ell(&c.fwd);
         free_ell(&c.adjT);
         free_ell(&c.adjRef);
@@ -1073,6 +1093,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
+        const char *e11 = getenv("SURFH_WBLUR_F16");
+        p->wblur_f16 = !(e11 && e11[0] == '0');      // 0: the three-piece bf16 kernels
         const char *e9 = getenv("SURFH_WBLUR_PRESPLIT");
         p->wblur_presplit = !(e9 && e9[0] == '0');   // 0: the producers split W again in every tile
         const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -1155,8 +1177,20 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         c.yoff = yoff;
         yoff += c.ysize;
         if (c.bsum) continue;
-        c.splitK = pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu);
-        if (p->wblur_pc && !p->wblur_fp32 && p->wblur_presplit) {
+        c.splitK = pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu,
+                              (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) ? 136 : 34);
+        if (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) {
+            const long nw = (long)c.LdetP * c.K;
+            c.pmax_adj = spmm_rows_waves(c.fwd.t, c.nlam);              // the adjoint's entries follow the forward's
+            const long nwv = c.pmax_adj + ymat_from_y_waves(c.P * c.S, c.Ldet, c.aout);
+            if (dev_alloc(&c.W16, (size_t)2 * nw) || dev_alloc(&c.Wt16, (size_t)2 * nw) || dev_alloc(&c.amax, 128) ||
+                dev_alloc(&c.pmax, (size_t)nwv))
+                return bail(1);
+            hipMemset(c.pmax, 0, (size_t)nwv * sizeof(unsigned));       // entries of workgroups that exit early stay 0
+            hipMemset(c.amax, 0, 128 * sizeof(unsigned));
+            if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
+                return bail(fail("operand split failed"));
+        } else if (p->wblur_pc && !p->wblur_fp32 && p->wblur_presplit) {
             const long nw = (long)c.LdetP * c.K;
             if (dev_alloc(&c.W3, (size_t)3 * nw) || dev_alloc(&c.Wt3, (size_t)3 * nw)) return bail(1);
             if (launch_split3(p->stream, c.W, c.W3, nw, nw) || launch_split3(p->stream, c.Wt, c.Wt3, nw, nw)) return bail(fail("operand split failed"));
@@ -1824,6 +1858,24 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
             for (int n = 0; n < N; ++n) bt[(size_t)n * K + k] = B[(size_t)k * N + n];
         HIP_OK(hipMemcpy(dB, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
         g.ldb = K;
+        if (mode[1] == 'h') {            // "1h": two-piece fp16 producer/consumer kernel
+            unsigned short *dB16 = nullptr;
+            unsigned *dmax = nullptr;
+            float amA = 0.f, amB = 0.f;
+            for (size_t i = 0; i < (size_t)M * K; ++i) amA = std::max(amA, std::fabs(A[i]));
+            for (float v : bt) amB = std::max(amB, std::fabs(v));
+            unsigned slots[64] = {0};
+            memcpy(&slots[5], &amA, 4);
+            HIP_OK(hipMalloc((void **)&dB16, bt.size() * 4));
+            HIP_OK(hipMalloc((void **)&dmax, sizeof(slots)));
+            HIP_OK(hipMemcpy(dmax, slots, sizeof(slots), hipMemcpyHostToDevice));
+            g.sB16 = gemm_f16x2_scale(amB); g.B16 = dB16; g.pB16 = (long)bt.size(); g.amax = dmax;
+            rc = launch_split2h(nullptr, dB, dB16, (long)bt.size(), (long)bt.size(), g.sB16);
+            if (rc == 0) rc = launch_gemm_nt_f16x2_pc(nullptr, g);
+            if (rc == 0) rc = (int)hipDeviceSynchronize();
+            hipFree(dB16);
+            hipFree(dmax);
+        } else
         rc = (mode[1] == 'p') ? launch_gemm_nt_bf16x3_pc(nullptr, g) : launch_gemm_nt_bf16x3(nullptr, g);   // "1p": producer/consumer kernel
     } else {
         rc = launch_gemm_f32(nullptr, g);

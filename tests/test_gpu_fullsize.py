@@ -48,14 +48,18 @@ def test_config2_dottest_and_linearity(c2):
     cfg, m = c2
     from surfh_amd import dotgap
     rng = np.random.default_rng(21)
-    gaps = []
+    gaps, ngaps = [], []
     for _ in range(5):
-        l, r = dotgap(m, rng)
+        v, u = rng.standard_normal(m.isize), rng.standard_normal(m.osize)
+        av = np.asarray(m.matvec(v), dtype=np.float64)
+        l, r = float(np.vdot(np.asarray(m.rmatvec(u), dtype=np.float64), v)), float(np.vdot(u, av))
         gaps.append(abs(l - r) / abs(r))
-    print("config2 dot-test gaps (randn)", gaps, flush=True)
-    # zero-mean test vectors: <u, A v> is a sum with heavy cancellation, so in fp32 the ratio has
-    # Cauchy tails; every draw meets aljabr's rtol=1e-5 criterion (test/sandbox_dottest.py:16-27)
-    assert max(gaps) < 1e-4 and np.median(gaps) < 5e-6
+        ngaps.append(abs(l - r) / (np.linalg.norm(u) * np.linalg.norm(av)))
+    print("config2 dot-test gaps (randn)", gaps, "normalised by |u||Av|", ngaps, flush=True)
+    # zero-mean test vectors: <u, A v> is a sum with heavy cancellation (|<u, Av>| ~ 1e-3 |u||Av|), so in fp32 the ratio
+    # |l - r| / |r| has Cauchy tails (one draw in five lands at 1e-4 with either GEMM); measured against the natural scale
+    # |u||Av| of the inner product the gap is at the 1e-8 level
+    assert max(ngaps) < 1e-6 and np.median(gaps) < 5e-6 and max(gaps) < 1e-3
     # non-negative test vectors (the physical regime: abundances and fluxes are >= 0): strict < 1e-6
     pg = []
     for _ in range(3):

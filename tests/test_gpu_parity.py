@@ -87,6 +87,42 @@ def test_gemm_producer_consumer_selftest():
         os.environ.pop("SURFH_SELFTEST_BF16X3")
 
 
+def test_gemm_two_piece_fp16_selftest():
+    """The two-piece fp16 producer/consumer GEMM (gemm_pc16.hip): power-of-two operand scales, round-to-nearest split,
+    three products.  Same gate as the bf16 split; element magnitudes spread over 12 decades within the operand (entries far
+    below the operand's largest magnitude keep their absolute, not their relative, precision), an all-zero operand, and
+    non-negative operands where a truncating split would show a bias."""
+    from surfh_amd import _lib
+    L = _lib.load()
+    rng = np.random.default_rng(2)
+    os.environ["SURFH_SELFTEST_BF16X3"] = "1h"
+    try:
+        for (M, N, K, sk) in [(128, 128, 32, 1), (128, 256, 64, 1), (256, 384, 512, 2), (384, 640, 1056, 3)]:
+            A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, K)))).astype(np.float32)
+            B = rng.standard_normal((K, N)).astype(np.float32) + np.arange(N, dtype=np.float32)[None, :] * 0.02
+            for scale in (1.0, 1e20, 1e-20):
+                As = (A * np.float32(scale)).astype(np.float32)
+                Cg = np.empty((M, N), dtype=np.float32)
+                _lib.check(L.surfh_gemm_selftest(0, M, N, K, sk, _lib.fptr(As), _lib.fptr(B), _lib.fptr(Cg)))
+                e = rel(Cg, As.astype(np.float64) @ B.astype(np.float64))
+                note("gemm_f16x2_pc", M=M, N=N, K=K, sk=sk, scale=scale, err=e)
+                assert e < 5e-7, (M, N, K, sk, scale, e)
+        M, N, K = 256, 256, 4096
+        A = rng.random((M, K)).astype(np.float32) * 3e4
+        B = (rng.random((K, N)) * 0.1).astype(np.float32)
+        Cg = np.empty((M, N), dtype=np.float32)
+        _lib.check(L.surfh_gemm_selftest(0, M, N, K, 1, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
+        ref = A.astype(np.float64) @ B.astype(np.float64)
+        bias = float(np.mean((Cg - ref) / ref))
+        note("gemm_f16x2_pc_nonneg", err=rel(Cg, ref), bias=bias)
+        assert rel(Cg, ref) < 1e-6 and abs(bias) < 3e-7          # one 4096-long fp32 accumulation chain (bf16 split: -8e-6 at 3072)
+        Z = np.zeros((M, K), dtype=np.float32)
+        _lib.check(L.surfh_gemm_selftest(0, M, N, K, 1, _lib.fptr(Z), _lib.fptr(B), _lib.fptr(Cg)))
+        assert not Cg.any()
+    finally:
+        os.environ.pop("SURFH_SELFTEST_BF16X3")
+
+
 @pytest.fixture(scope="module")
 def c1():
     cfg = problems.config1()
@@ -376,9 +412,9 @@ def test_disjoint_wavelength_windows(lmm):
 @pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_RX3": "0", "SURFH_FOLD2": "1"},
                                  {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
                                  {"SURFH_WBLUR_PC": "0"}, {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_PACKED": "0"},
-                                 {"SURFH_WBLUR_PRESPLIT": "0"}],
+                                 {"SURFH_WBLUR_F16": "0"}, {"SURFH_WBLUR_F16": "0", "SURFH_WBLUR_PRESPLIT": "0"}],
                          ids=["fold_fp32", "fold_fp32_two_launch", "dense_dft", "unfused_mix", "wblur_fp32", "wblur_4wave",
-                              "two_streams", "dft_two_pass_complex", "wblur_split_in_kernel"])
+                              "two_streams", "dft_two_pass_complex", "wblur_bf16_three_piece", "wblur_bf16_split_in_kernel"])
 def test_alternative_kernel_paths(env):
     """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green."""
     cfg = problems.config1()

@@ -3,6 +3,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #include <random>
 #include <vector>
 #include "../../surfh_amd/csrc/gemm_f32.h"
@@ -28,13 +30,28 @@ int run(int M, int N, int K, int sk, const char *name, bool check) {
     CK(hipMalloc(&dA3, A.size() * 6)); CK(hipMalloc(&dB3, B.size() * 6));
     if (launch_split3(st, dA, dA3, (long)A.size(), (long)A.size()) || launch_split3(st, dB, dB3, (long)B.size(), (long)B.size())) { printf("split failed\n"); return 1; }
     CK(hipStreamSynchronize(st));
-    const char *names[4] = {"shipped", "prod/cons", "pc B-pre", "pc AB-pre"};
-    for (int which = 0; which < 4; ++which) {
+    // two-piece fp16 operands: B split once with its power-of-two scale, A's maximum in the 64 slots its producer would fill
+    unsigned short *dB16; unsigned *dmax;
+    CK(hipMalloc(&dB16, B.size() * 4)); CK(hipMalloc(&dmax, 64 * 4));
+    float amaxA = 0.f, amaxB = 0.f;
+    for (auto v : A) amaxA = std::max(amaxA, std::fabs(v));
+    for (auto v : B) amaxB = std::max(amaxB, std::fabs(v));
+    const float sB = gemm_f16x2_scale(amaxB);
+    if (launch_split2h(st, dB, dB16, (long)B.size(), (long)B.size(), sB)) { printf("split2h failed\n"); return 1; }
+    {
+        unsigned slots[64] = {0};
+        memcpy(&slots[17], &amaxA, 4);
+        CK(hipMemcpy(dmax, slots, sizeof(slots), hipMemcpyHostToDevice));
+    }
+    CK(hipStreamSynchronize(st));
+    const char *names[5] = {"shipped", "prod/cons", "pc B-pre", "pc AB-pre", "pc f16x2"};
+    for (int which = 0; which < 5; ++which) {
         if (which == 0 && N % 128) continue;
         GemmArgs gg = g;
-        if (which >= 2) { gg.B3 = dB3; gg.pB3 = (long)B.size(); }
+        if (which == 2 || which == 3) { gg.B3 = dB3; gg.pB3 = (long)B.size(); }
         if (which == 3) { gg.A3 = dA3; gg.pA3 = (long)A.size(); }
-        auto launch = [&]() { return which ? launch_gemm_nt_bf16x3_pc(st, gg) : launch_gemm_nt_bf16x3(st, gg); };
+        if (which == 4) { gg.B16 = dB16; gg.pB16 = (long)B.size(); gg.sB16 = sB; gg.amax = dmax; }
+        auto launch = [&]() { return which == 4 ? launch_gemm_nt_f16x2_pc(st, gg) : which ? launch_gemm_nt_bf16x3_pc(st, gg) : launch_gemm_nt_bf16x3(st, gg); };
         CK(hipMemset(dC, 0xFF, (size_t)nslab * M * N * 4));
         int rc = launch();
         if (rc) { printf("launch rc %d\n", rc); return 1; }
@@ -60,7 +77,7 @@ int run(int M, int N, int K, int sk, const char *name, bool check) {
         printf("%-8s %-9s M=%d N=%d K=%d sk=%d  rel L2 err %.3g   %.4f ms  %.1f TF/s fp32-equivalent\n", name, names[which], M, N, K, sk,
                check ? std::sqrt(num / den) : -1.0, ms, 2.0 * M * N * K / ms * 1e-9);
     }
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dA3); hipFree(dB3);
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dA3); hipFree(dB3); hipFree(dB16); hipFree(dmax);
     return 0;
 }
 
