@@ -17,13 +17,14 @@
  *     available from surfh_last_error() (thread-local, valid until the next call).
  *   - the geometry tables are produced by the host side (surfh_amd/geometry.py),
  *     which restates instru.py / slicer.py; the library only consumes them.
- *   - arithmetic type: fp32 on device.  The dense stages (spectral blur, DFT passes) evaluate every fp32
- *     product exactly as six bf16 matrix-core products of a three-way operand split, accumulated in fp32
- *     (fp32-input MFMA kernels behind SURFH_* environment switches); inner products of the solvers accumulate
- *     in fp64.
+ *   - arithmetic type: fp32 on device.  The dense stages evaluate every fp32 product as a few 16-bit
+ *     matrix-core products of split operands, accumulated in fp32: the spectral blur as three products of a
+ *     two-piece round-to-nearest fp16 split (22 mantissa bits), the DFT passes as six products of an exact
+ *     three-piece bf16 split (fp32-input MFMA kernels behind SURFH_* environment switches); inner products
+ *     of the solvers accumulate in fp64.
  *   - environment switches read at plan creation (A/B paths, all parity-tested): SURFH_DFT_RX3=0,
  *     SURFH_FOLD2=1, SURFH_DFT_DENSE=1, SURFH_NO_FUSED_MIX=1, SURFH_DFT_PACKED=0, SURFH_WBLUR_FP32=1,
- *     SURFH_WBLUR_PC=0, SURFH_WBLUR_PRESPLIT=0, SURFH_OVERLAP=1.
+ *     SURFH_WBLUR_F16=0, SURFH_WBLUR_PC=0, SURFH_WBLUR_PRESPLIT=0, SURFH_OVERLAP=1.
  */
 #ifndef SURFH_AMD_H
 #define SURFH_AMD_H
