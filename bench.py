@@ -274,6 +274,22 @@ def main():
                                               "frac": ach / HBM_PEAK_GBS, "kernel": "+".join(sorted(k for k, _ in dft)),
                                               "launches": n_l, "avg_ms": t_s * 1e3 / n_l,
                                               "traffic": pmc.get("dft_rx3_kernel", {}).get("hbm_bytes_per_launch")}
+        # the matrix-core half of the path, whichever group dominates: R / R^T against the fp32-MFMA peak
+        gm = [(k, v) for k, v in (groups if dom_prefix == "gemm_wblur" else groups_all).items() if k.startswith("gemm_nt")]
+        if gm:
+            n_l = sum(v[0] for _, v in gm)
+            t_s = sum(v[1] for _, v in gm) * 1e-3
+            steps_seen = args.steps if dom_prefix == "gemm_wblur" else max(n_all, 1)
+            flops_step = sum(2.0 * 2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
+                             for c in m.channels)
+            ach = flops_step * steps_seen / t_s / 1e12
+            nprod = 3.0 if gm[0][0].startswith("gemm_nt_f16x2") else 6.0
+            out["roofline_spectral_blur_gemm"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                                                  "frac": ach / MFMA_F32_PEAK_TF, "kernel": gm[0][0], "launches": n_l,
+                                                  "avg_ms": t_s * 1e3 / n_l,
+                                                  "matrix_core_16bit_tflops": nprod * ach,
+                                                  "matrix_core_16bit_peak_frac": nprod * ach / 2500.0,
+                                                  "traffic": pmc.get(gm[0][0], {}).get("hbm_bytes_per_launch")}
         if world == 1 and args.cpu_seconds > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)
