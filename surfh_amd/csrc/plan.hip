@@ -130,6 +130,7 @@ struct surfh_plan {
     bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
     bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
     bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
+    bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
@@ -357,6 +358,26 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
             f2.dst.push_back(row.first);
         }
         f = std::move(f2);
+    }
+    if (p->gather_sorted) {
+        // Order the gather rows by the cube pixel of their first tap.  In (pointing, alpha, beta) order the four dither
+        // pointings, which cover the same pixels shifted by a few columns, are a quarter of the table apart: every pixel
+        // was fetched from HBM once per pointing (measured 0.525 GB per launch for a 0.15 GB window).  Sorted, the rows
+        // that share taps run together on one XCD and hit its L2.
+        std::vector<size_t> ord(f.rows.size());
+        for (size_t i = 0; i < ord.size(); ++i) ord[i] = i;
+        std::stable_sort(ord.begin(), ord.end(), [&](size_t a, size_t b) {
+            const int64_t ka = f.rows[a].empty() ? INT64_MAX : f.rows[a][0].first, kb = f.rows[b].empty() ? INT64_MAX : f.rows[b][0].first;
+            return ka < kb;
+        });
+        HostEll g;
+        g.rows.reserve(ord.size());
+        g.dst.reserve(ord.size());
+        for (size_t i : ord) {
+            g.rows.push_back(std::move(f.rows[i]));
+            g.dst.push_back(f.dst[i]);
+        }
+        f = std::move(g);
     }
     if (upload_ell(f, &c->fwd)) return 1;
 
@@ -1093,6 +1114,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
+        const char *e12 = getenv("SURFH_GATHER_SORTED");
+        p->gather_sorted = !(e12 && e12[0] == '0');   // 0: gather rows in (pointing, alpha, beta) order
         const char *e11 = getenv("SURFH_WBLUR_F16");
         p->wblur_f16 = !(e11 && e11[0] == '0');      // 0: the three-piece bf16 kernels
         const char *e9 = getenv("SURFH_WBLUR_PRESPLIT");
