@@ -125,6 +125,39 @@ def test_config2_solvers_agree_and_projections(c2):
     ch.close()
 
 
+def test_two_band_overlap_full_size():
+    """Two real bands (2A, 2B) whose wavelength windows overlap, at the benchmark's spatial size (a slice of BASELINE
+    config 3 the float64 oracle finishes in half a minute): forward and exact adjoint against the oracle, the dot test,
+    and the adjoint's additive overlap (spectroModel.py:176)."""
+    N, Lc = 251, 768
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    specs = [problems.band_spec("2a"), problems.band_spec("2b")]
+    wav = np.linspace(7.41, 10.23, Lc)
+    cfg = dict(N=N, Lc=Lc, alpha_axis=ax, beta_axis=ax.copy(), wavel=wav, specs=specs, templates=orc.synthetic_templates(Lc),
+               sotf=orc.ir2fr(orc.gaussian_psf(wav, problems.STEP), (N, N)),
+               pointings=[orc.dither4(sp.det_pix_size, sp.beta_width / sp.n_slit) for sp in specs],
+               maps=np.random.default_rng(19940407).random((4, N, N)), step_deg=problems.STEP_DEG)
+    m = build_model(cfg, with_ref=False)
+    try:
+        w = [(c.wslice.start, c.wslice.stop) for c in m.channels]
+        assert w[0][1] > w[1][0]                                    # the windows do overlap
+        t = time.time()
+        om = problems.oracle_model(cfg, box="direct")
+        yo = om.forward(cfg["maps"])
+        rng = np.random.default_rng(12)
+        u = rng.random(yo.shape)
+        ao = om.adjoint(u)
+        print(f"two-band oracle forward + adjoint {time.time() - t:.0f}s, windows {w}", flush=True)
+        y, a = m.forward(cfg["maps"]), m.adjoint(u)
+        v = rng.random(m.ishape)
+        l = float(np.vdot(m.adjoint(u), v)); r = float(np.vdot(u, m.forward(v)))
+        e = dict(fwd=rel(y, yo), adj=rel(a, ao), dot=abs(l - r) / abs(r))
+        print("two-band full size", e, flush=True)
+        assert e["fwd"] < 1e-5 and e["adj"] < 1e-5 and e["dot"] < 1e-6
+    finally:
+        m.close()
+
+
 @pytest.mark.parametrize("N,Lc", [(300, 96), (501, 64)], ids=["even_300", "driver_default_501"])
 def test_other_image_sizes(N, Lc):
     """Image sizes other than the benchmark's 251: an even size with two row tiles per DFT pass (N/2+1 = 151 > 128) and
