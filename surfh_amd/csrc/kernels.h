@@ -33,6 +33,9 @@ struct EllTable {
     const int64_t *col = nullptr;  // [R][W]  source offset (floats) of wavelength 0
     const float *val = nullptr;    // [R][W]
     const int64_t *dst_off = nullptr;  // [R]
+    // accumulate mode only, optional: bit j of rmw[r] set = the 1024-wavelength chunk j of row r may already hold another
+    // table's contribution and is read-modify-written; clear = the destination is known to be zero, plain store
+    const uint32_t *rmw = nullptr;
 };
 // pmax / slots (optional, gather mode only): every wave stores max |output| (bit pattern) in its entry of pmax
 // [spmm_rows_waves()], a one-workgroup pass then leaves the overall maximum in slots[0..63] -- the scale of the data

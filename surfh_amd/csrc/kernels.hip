@@ -299,7 +299,7 @@ __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float 
             acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
         }
         float4 *p = reinterpret_cast<float4 *>(dst + t.dst_off[r] + l4);
-        if (accumulate) {
+        if (accumulate && (!t.rmw || ((t.rmw[r] >> blockIdx.y) & 1u))) {      // workgroup-uniform
             const float4 o = *p;
             acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
         }

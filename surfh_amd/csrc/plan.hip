@@ -67,6 +67,8 @@ struct DevEll {
     int32_t *cnt = nullptr;
     int64_t *col = nullptr, *dst = nullptr;
     float *val = nullptr;
+    uint32_t *rmw = nullptr;            // scatter tables: chunks of a row that need read-modify-write (EllTable::rmw)
+    std::vector<int64_t> host_dst;      // kept for the scatter tables until the plan is complete
 };
 
 struct Channel {
@@ -255,6 +257,7 @@ int upload_ell(const HostEll &h, DevEll *d) {
 }
 
 void free_ell(DevEll *d) {
+    hipFree(d->rmw);
     hipFree(d->cnt);
     hipFree(d->col);
     hipFree(d->val);
@@ -394,6 +397,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
             t.dst.push_back(px.first);
         }
         if (upload_ell(t, &c->adjT)) return 1;
+        c->adjT.host_dst = t.dst;
     }
 
     // ---- reference-compatible back-interpolation (gridding_t) ---------------------------------
@@ -1222,6 +1226,39 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));
     }
     p->osize = yoff;
+    {   // The adjoint scatters channel after channel into the cleared cube.  A (pixel, 1024-wavelength chunk) of channel c
+        // must be read-modify-written only if an earlier channel's table has that pixel and its window reaches into the
+        // chunk; everywhere else the destination is still zero and the kernel stores without reading (the windows of
+        // adjacent bands overlap by a tenth, so most of the traffic is of the second kind).
+        const long npixrows = (long)p->NBP * p->NAP;
+        std::vector<std::vector<uint8_t>> touched(p->ch.size());
+        for (size_t ci = 0; ci < p->ch.size(); ++ci) {
+            Channel &c = p->ch[ci];
+            const std::vector<int64_t> &dst = c.adjT.host_dst;
+            touched[ci].assign((size_t)npixrows, 0);
+            const int nchunk = (c.nlam / 4 + 255) / 256;
+            std::vector<uint32_t> mask(dst.size(), nchunk > 32 ? 0xFFFFFFFFu : 0u);
+            for (size_t r = 0; r < dst.size(); ++r) {
+                const long pix = (dst[r] - c.ws0a) / p->LP;
+                if (pix < 0 || pix >= npixrows) return bail(fail("scatter table: bad destination"));
+                touched[ci][pix] = 1;
+                if (nchunk > 32) continue;
+                for (size_t cj = 0; cj < ci; ++cj) {
+                    if (!touched[cj][pix]) continue;
+                    const Channel &o = p->ch[cj];
+                    for (int j = 0; j < nchunk; ++j) {
+                        const int lo = c.ws0a + 1024 * j, hi = std::min(c.ws0a + c.nlam, lo + 1024);
+                        if (lo < o.ws0a + o.nlam && o.ws0a < hi) mask[r] |= 1u << j;
+                    }
+                }
+            }
+            if (dev_upload(&c.adjT.rmw, mask)) return bail(1);
+            const char *ea = getenv("SURFH_SCATTER_RMW_ALL");
+            if (!(ea && ea[0] == '1')) c.adjT.t.rmw = c.adjT.rmw;        // 1: read-modify-write everywhere (A/B)
+            c.adjT.host_dst.clear();
+            c.adjT.host_dst.shrink_to_fit();
+        }
+    }
     if (dev_alloc(&p->io_x, (size_t)p->isize) || dev_alloc(&p->io_y, (size_t)p->osize) || dev_alloc(&p->cg_y, (size_t)p->osize) ||
         dev_alloc(&p->dscal, 8) || dev_alloc(&p->dscratch, 1024))
         return bail(1);
