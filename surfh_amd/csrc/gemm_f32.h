@@ -27,11 +27,11 @@ struct GemmArgs {
     // element (m,k) at A3[q*pA3 + m*lda + k].  B3 alone (a constant operand split once) or both may be given.
     const unsigned short *A3 = nullptr, *B3 = nullptr;
     long pA3 = 0, pB3 = 0;
-    // two-piece fp16 kernel (gemm_pc16.hip): B as its fp16 pieces B16[q*pB16 + n*ldb + k] of B / sB16; the scale of A
-    // derived on the device from the 64 max slots `amax` its producer filled, or fixed (sA16) when amax is NULL
+    // two-piece fp16 kernel (gemm_pc16.hip): B as its fp16 pieces B16[q*pB16 + n*ldb + k] of B / sB16; the scales of A
+    // (one per row) derived on the device from amax[batch][M] = max |A[m][:]| as bit patterns
     const unsigned short *B16 = nullptr;
     long pB16 = 0;
-    float sB16 = 0.f, sA16 = 0.f;
+    float sB16 = 0.f;
     const unsigned *amax = nullptr;
 };
 

@@ -10,8 +10,10 @@
 // tenth of the six-product truncating bf16 split (which also carries a -4e-8 bias on non-negative data), for half the
 // matrix-core work.  What remains is the fp32 accumulation itself.
 //   * B is constant on this path (the spectral PSF): split once at plan creation (launch_split2h), scale sB a host constant.
-//   * A is data: the kernel that writes it leaves max|A| in 64 slots (unsigned bit patterns, atomicMax); every workgroup
-//     derives the power-of-two scale from them, the producers split on the fly.
+//   * A is data: one scale PER ROW, so that an outlier in one row (a hot detector pixel) does not cost the other rows their
+//     precision.  The kernel that writes A leaves per-wave maxima, a small pass reduces them to max|A[m][:]| per row (bit
+//     patterns of non-negative floats); the producers derive each row's power of two and split on the fly, the consumers
+//     undo it when they store.
 #include "gemm_f32.h"
 #include "lds_attr.h"
 #include <cmath>
@@ -63,23 +65,16 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_pc_kernel(GemmArgs g) {
     const int b = z / g.splitK, sk = z % g.splitK;
     const int m0 = tm * BM, n0 = tn * BN;
     const int Kper = g.K / g.splitK, kbeg = sk * Kper, nk = Kper / BK;
-    // scale of the data operand from the 64 max slots (bit patterns of non-negative floats order like the floats)
-    unsigned mx = g.amax ? g.amax[lane] : 0u;
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const unsigned other = (unsigned)__shfl_xor((int)mx, o, 64);
-        mx = other > mx ? other : mx;
-    }
-    const float sA = g.amax ? scale_of(__uint_as_float(mx)) : g.sA16;
+    const unsigned *rmax = g.amax + (long)b * g.M + m0;              // max |A[m][:]| of this tile's rows (bit patterns)
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
         const int t = tid - 256;
-        const float inv = 1.f / sA;                               // exact: a power of two
         const int r = t >> 3, c8 = t & 7;
         const int rs = t >> 2, c4 = t & 3;
         const float *fsrc[NF];
         int fpos[NF];
+        float finv[NF];                                           // 1 / scale of the row: exact, a power of two
         const unsigned short *ssrc[NS];
         int spos[NS];
         const float *Ab = g.A0 + (long)b * g.sA + kbeg + 4 * c8;
@@ -88,6 +83,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_pc_kernel(GemmArgs g) {
             const int row = r + 32 * i;
             fsrc[i] = Ab + (long)(m0 + row) * g.lda;
             fpos[i] = row * BK + (((c8 >> 1) ^ ((row >> 2) & 3)) * 8) + (c8 & 1) * 4;
+            finv[i] = 1.f / scale_of(__uint_as_float(rmax[row]));
         }
 #pragma unroll
         for (int p = 0; p < NSP; ++p) {
@@ -111,7 +107,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_pc_kernel(GemmArgs g) {
 #define PH_STORE(st_, f_, s_)                                                                                           \
     {                                                                                                                   \
         unsigned short *base = lds + (st_) * STAGE;                                                                     \
-        _Pragma("unroll") for (int i = 0; i < NF; ++i) store_split(base + fpos[i], f_[i], inv);                         \
+        _Pragma("unroll") for (int i = 0; i < NF; ++i) store_split(base + fpos[i], f_[i], finv[i]);                     \
         _Pragma("unroll") for (int i = 0; i < NS; ++i) *reinterpret_cast<u32x4 *>(base + spos[i]) = s_[i];              \
     }
         PH_LOAD(0, fcur, scur);
@@ -178,13 +174,19 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_pc_kernel(GemmArgs g) {
     }
     __builtin_amdgcn_s_setprio(0);
     {
-        const float sc = sA * g.sB16;                             // undo both operand scales (powers of two: exact)
+        // undo both operand scales (powers of two: exact); all 32 row maxima of this lane requested together
+        unsigned rm[2][16];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rm[i][r] = rmax[wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
         unsigned o_ = cbase;
         asm volatile("" : "+v"(o_));
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
+                const float sc = scale_of(__uint_as_float(rm[i][r])) * g.sB16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     if (n0 + wn * 128 + j * 32 + l31 < g.N) *reinterpret_cast<float *>(Cb + (o_ + 128u * j)) = acc[i][j][r] * sc;
@@ -230,10 +232,10 @@ int launch_split2h(hipStream_t stream, const float *src, unsigned short *dst2, l
 }
 
 // C[M][N] = A[M][K] * B[N][K]^T ; M multiple of 128, N of 128 (ragged last 256-column tile handled), K of 32*splitK.
-// B as fp16 pieces (g.B16, g.pB16, g.sB16); A fp32 with its max slots g.amax (or a fixed scale g.sA16 when amax is NULL).
+// B as fp16 pieces (g.B16, g.pB16, g.sB16); A fp32 with its per-row maxima g.amax[batch][M] (bit patterns).
 int launch_gemm_nt_f16x2_pc(hipStream_t stream, const GemmArgs &g) {
     if (g.M % BM || g.N % 128 || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1 || g.accumulate || g.lda % 4 || g.ldb % 8 ||
-        !g.B16 || g.pB16 % 8 || !(g.sB16 > 0.f) || (!g.amax && !(g.sA16 > 0.f)))
+        !g.B16 || g.pB16 % 8 || !(g.sB16 > 0.f) || !g.amax)
         return (int)hipErrorInvalidValue;
     if ((double)(BM + 1) * (double)g.ldc * 4.0 >= 2147483648.0) return (int)hipErrorInvalidValue;
     const long total = (long)(g.M / BM) * ((g.N + BN - 1) / BN) * g.batch * g.splitK;

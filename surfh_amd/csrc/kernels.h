@@ -37,12 +37,15 @@ struct EllTable {
     // table's contribution and is read-modify-written; clear = the destination is known to be zero, plain store
     const uint32_t *rmw = nullptr;
 };
-// pmax / slots (optional, gather mode only): every wave stores max |output| (bit pattern) in its entry of pmax
-// [spmm_rows_waves()], a one-workgroup pass then leaves the overall maximum in slots[0..63] -- the scale of the data
-// operand of the two-piece fp16 GEMM (gemm_pc16.hip)
+// pmax ... rowmax (optional, gather mode only): every wave stores max |output| (bit pattern) in its entry of pmax
+// [spmm_rows_waves()]; a second pass takes, for every row of the [NP][K] operand the table writes, the maximum over the
+// entries listed in rowptr / idx (built once with spmm_rows_entry) -- the per-row scales of the data operand of the
+// two-piece fp16 GEMM (gemm_pc16.hip)
 int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate,
-                     unsigned *pmax = nullptr, unsigned *slots = nullptr);
+                     unsigned *pmax = nullptr, const int *rowptr = nullptr, const int *idx = nullptr, unsigned *rowmax = nullptr,
+                     int NP = 0);
 long spmm_rows_waves(const EllTable &t, int nlam);
+long spmm_rows_entry(const EllTable &t, int r, int chunk, int wave);
 long ymat_from_y_waves(int PS, int Ldet, int aout);
 
 // [L][Na][Nb] (wavelength-major, the reference's cube layout) <-> [NBP][NAP][LP] (wavelength innermost)
@@ -57,7 +60,7 @@ int launch_y_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit
                         int aout, int LdetP);
 // ymat[(ps*aout + a)*LdetP + l] = y[(ps*Ldet + l)*aout + a]
 int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP, unsigned *pmax = nullptr,
-                       unsigned *slots = nullptr);
+                       unsigned *rowmax = nullptr, int NP = 0);
 int launch_fill_zero(hipStream_t s, float *p, long n);
 
 // ---- CG vector kernels (qmm.lcg loop body; fusion_CT.py:16-43 priors) --------------------------

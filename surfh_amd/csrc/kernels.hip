@@ -253,23 +253,31 @@ __device__ __forceinline__ void wave_amax_store(float m, unsigned *pmax, unsigne
     if ((threadIdx.x & 63) == 0) pmax[wave_id] = __float_as_uint(m);
 }
 
-// 64 workgroups, one slot each (the GEMM takes the maximum over the 64 slots)
-__global__ __launch_bounds__(1024) void amax_reduce_kernel(const unsigned *__restrict__ pmax, long n, unsigned *__restrict__ slots) {
+// per-wave maxima -> max |A[m][:]| per GEMM row.  ymat: the entries of a row are contiguous (one thread per row).
+__global__ __launch_bounds__(TPB) void rowmax_contiguous_kernel(const unsigned *__restrict__ pmax, int per_row, int nrows, int NP,
+                                                                unsigned *__restrict__ rowmax) {
+    const int n = blockIdx.x * TPB + threadIdx.x;
+    if (n >= NP) return;
     unsigned m = 0;
-    for (long i = (long)blockIdx.x * 1024 + threadIdx.x; i < n; i += (long)gridDim.x * 1024) m = max(m, pmax[i]);
+    if (n < nrows)
+        for (int i = 0; i < per_row; ++i) m = max(m, pmax[(long)n * per_row + i]);
+    rowmax[n] = m;                                                   // padding rows of the operand are zero
+}
+
+// gather: the per-wave entries of a GEMM row are scattered over the launch grid; their indices were listed at plan creation
+// (rowptr / idx).  One wave per row, no atomics (an atomicMax per wave inside the gather cost 0.1 ms per launch).
+__global__ __launch_bounds__(TPB) void rowmax_csr_kernel(const unsigned *__restrict__ pmax, const int *__restrict__ rowptr,
+                                                         const int *__restrict__ idx, int NP, unsigned *__restrict__ rowmax) {
+    const int row = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= NP) return;
+    unsigned m = 0;
+    for (int e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) m = max(m, pmax[idx[e]]);
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    __shared__ unsigned sm[16];
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        unsigned v = threadIdx.x < 16 ? sm[threadIdx.x] : 0u;
-        for (int o = 8; o > 0; o >>= 1) v = max(v, (unsigned)__shfl_xor((int)v, o, 64));
-        if (threadIdx.x == 0) slots[blockIdx.x] = v;
-    }
+    if (lane == 0) rowmax[row] = m;
 }
 
 __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float *__restrict__ src,
-                                                        float *__restrict__ dst, int nlam, int accumulate, unsigned *amax) {
+                                                        float *__restrict__ dst, int nlam, int accumulate, unsigned *pmax) {
     // workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD one
     // contiguous band of table rows, so neighbouring rows -- which share most of their taps -- hit the same L2
     const int per = (t.R + 7) / 8;
@@ -305,8 +313,8 @@ __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float 
         }
         *p = acc;
     }
-    if (amax)       // lanes beyond the window carry 0; the whole wave takes part in the reduction
-        wave_amax_store(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))), amax,
+    if (pmax)       // lanes beyond the window carry 0; the whole wave takes part in the reduction
+        wave_amax_store(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))), pmax,
                         (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
@@ -717,18 +725,26 @@ __global__ __launch_bounds__(TPB) void lmm_cube2maps_kernel(const float *__restr
 
 }  // namespace
 
+long ymat_from_y_waves(int PS, int Ldet, int aout) { return (long)((Ldet + TPB - 1) / TPB) * PS * aout * (TPB / 64); }
+
 long spmm_rows_waves(const EllTable &t, int nlam) {
     return (long)((t.R + 7) / 8 * 8) * ((nlam / 4 + TPB - 1) / TPB) * (TPB / 64);
 }
-long ymat_from_y_waves(int PS, int Ldet, int aout) { return (long)((Ldet + TPB - 1) / TPB) * PS * aout * (TPB / 64); }
+// index of the pmax entry of wave `wave` of the workgroup that handles table row r, chunk `chunk` (the kernel's XCD banding)
+long spmm_rows_entry(const EllTable &t, int r, int chunk, int wave) {
+    const int per = (t.R + 7) / 8, gx = (t.R + 7) / 8 * 8;
+    const int bx = (r % per) * 8 + r / per;
+    return ((long)chunk * gx + bx) * (TPB / 64) + wave;
+}
 
 int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate, unsigned *pmax,
-                     unsigned *slots) {
+                     const int *rowptr, const int *idx, unsigned *rowmax, int NP) {
     if (t.R == 0 || nlam <= 0) return 0;
-    if (nlam % 4 || (pmax && (accumulate || !slots))) return (int)hipErrorInvalidValue;
+    if (nlam % 4 || (pmax && (accumulate || !rowptr || !idx || !rowmax || NP <= 0))) return (int)hipErrorInvalidValue;
     dim3 grid((t.R + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
     hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate, pmax);
-    if (pmax) hipLaunchKernelGGL(amax_reduce_kernel, dim3(64), dim3(1024), 0, s, pmax, spmm_rows_waves(t, nlam), slots);
+    if (pmax)
+        hipLaunchKernelGGL(rowmax_csr_kernel, dim3((NP + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, pmax, rowptr, idx, NP, rowmax);
     return (int)hipGetLastError();
 }
 
@@ -765,11 +781,13 @@ int launch_y_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit
 }
 
 int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int Ldet, int aout, int LdetP, unsigned *pmax,
-                       unsigned *slots) {
-    if (pmax && !slots) return (int)hipErrorInvalidValue;
+                       unsigned *rowmax, int NP) {
+    if (pmax && (!rowmax || NP < PS * aout)) return (int)hipErrorInvalidValue;
     dim3 grid((Ldet + TPB - 1) / TPB, PS * aout);
     hipLaunchKernelGGL(ymat_from_y_kernel, grid, dim3(TPB), 0, s, y, ymat, PS, Ldet, aout, LdetP, pmax);
-    if (pmax) hipLaunchKernelGGL(amax_reduce_kernel, dim3(64), dim3(1024), 0, s, pmax, ymat_from_y_waves(PS, Ldet, aout), slots);
+    if (pmax)
+        hipLaunchKernelGGL(rowmax_contiguous_kernel, dim3((NP + TPB - 1) / TPB), dim3(TPB), 0, s, pmax, (int)grid.x * (TPB / 64), PS * aout,
+                           NP, rowmax);
     return (int)hipGetLastError();
 }
 

@@ -85,9 +85,11 @@ struct Channel {
     unsigned short *W3 = nullptr, *Wt3 = nullptr;   // the two constant GEMM operands cut once into their bf16 pieces [3][rows][cols]
     unsigned short *W16 = nullptr, *Wt16 = nullptr; // ... or into their two fp16 pieces [2][rows][cols] of W / sW (gemm_pc16.hip)
     float sW = 1.f;
-    unsigned *amax = nullptr;                       // [2][64] max slots of the data operands: Xs (forward), ymat (adjoint)
+    unsigned *amax = nullptr;                       // [2][NP] max |row| of the data operands: Xs (forward), ymat (adjoint)
     unsigned *pmax = nullptr;                       // per-wave maxima of the kernel that wrote the operand (reduced into amax)
-    long pmax_adj = 0;
+    long pmax_adj = 0;                              // the adjoint's entries follow the forward's
+    int *rm_ptr = nullptr, *rm_idx = nullptr;       // forward: pmax entries of every GEMM row (CSR)
+    std::vector<int64_t> fwd_dst;                   // destinations of the gather rows, kept until the CSR is built
     DevEll fwd, adjT, adjRef;
     bool has_ref = false;
     bool bsum = false;   // no spectral blur: y[l][(p,s,a)] = sum over the slit's beta columns (MRSBlurred)
@@ -383,6 +385,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
         f = std::move(g);
     }
     if (upload_ell(f, &c->fwd)) return 1;
+    c->fwd_dst = f.dst;
 
     // ---- exact transpose: rows = touched cube pixels ------------------------------------------
     {
@@ -824,7 +827,8 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
         const bool f16 = c.W16 != nullptr;
         {
             Prof pr(p, "spmm_gather_fwd");
-            LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, f16 ? c.amax : nullptr));
+            LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, c.rm_ptr, c.rm_idx,
+                                       f16 ? c.amax : nullptr, c.NP));
         }
         if (c.bsum) {   // y[l][(p,s,a)] = Xs[(p,s,a)][l]
             Prof pr(p, "y_transpose");
@@ -883,7 +887,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
         {
             Prof pr(p, "ymat_from_y", sB);
             LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax + c.pmax_adj : nullptr,
-                                         f16 ? c.amax + 64 : nullptr));
+                                         f16 ? c.amax + c.NP : nullptr, c.NP));
         }
         GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
         g.A0 = c.ymat; g.lda = c.LdetP;
@@ -897,7 +901,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             } else {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
                 g.B3 = c.Wt3; g.pB3 = (long)c.LdetP * c.K;
-                g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax + 64;
+                g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax + c.NP;
                 LAUNCH_OK(f16 ? launch_gemm_nt_f16x2_pc(sB, g) : p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
@@ -972,6 +976,8 @@ int surfh_plan_destroy(surfh_plan *p) {
         hipFree(c.Wt16);
         hipFree(c.amax);
         hipFree(c.pmax);
+        hipFree(c.rm_ptr);
+        hipFree(c.rm_idx);
         free_ell(&c.fwd);
         free_ell(&c.adjT);
         free_ell(&c.adjRef);
@@ -1208,13 +1214,30 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                               (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) ? 136 : 34);
         if (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) {
             const long nw = (long)c.LdetP * c.K;
-            c.pmax_adj = spmm_rows_waves(c.fwd.t, c.nlam);              // the adjoint's entries follow the forward's
+            c.pmax_adj = spmm_rows_waves(c.fwd.t, c.nlam);
             const long nwv = c.pmax_adj + ymat_from_y_waves(c.P * c.S, c.Ldet, c.aout);
-            if (dev_alloc(&c.W16, (size_t)2 * nw) || dev_alloc(&c.Wt16, (size_t)2 * nw) || dev_alloc(&c.amax, 128) ||
+            {   // pmax entries of every GEMM row: gather row r writes into GEMM row dst / K
+                const int chunks = (c.nlam / 4 + 255) / 256;
+                std::vector<std::vector<int>> per((size_t)c.NP);
+                for (size_t r = 0; r < c.fwd_dst.size(); ++r) {
+                    const long row = c.fwd_dst[r] / c.K;
+                    if (row < 0 || row >= c.NP) return bail(fail("gather destination outside the operand"));
+                    for (int ck = 0; ck < chunks; ++ck)
+                        for (int w = 0; w < 4; ++w) per[row].push_back((int)spmm_rows_entry(c.fwd.t, (int)r, ck, w));
+                }
+                std::vector<int> ptr((size_t)c.NP + 1, 0), idx;
+                for (int m = 0; m < c.NP; ++m) {
+                    ptr[m + 1] = ptr[m] + (int)per[m].size();
+                    idx.insert(idx.end(), per[m].begin(), per[m].end());
+                }
+                if (idx.empty()) idx.push_back(0);
+                if (dev_upload(&c.rm_ptr, ptr) || dev_upload(&c.rm_idx, idx)) return bail(1);
+            }
+            if (dev_alloc(&c.W16, (size_t)2 * nw) || dev_alloc(&c.Wt16, (size_t)2 * nw) || dev_alloc(&c.amax, (size_t)2 * c.NP) ||
                 dev_alloc(&c.pmax, (size_t)nwv))
                 return bail(1);
             hipMemset(c.pmax, 0, (size_t)nwv * sizeof(unsigned));       // entries of workgroups that exit early stay 0
-            hipMemset(c.amax, 0, 128 * sizeof(unsigned));
+            hipMemset(c.amax, 0, (size_t)2 * c.NP * sizeof(unsigned));
             if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
                 return bail(fail("operand split failed"));
         } else if (p->wblur_pc && !p->wblur_fp32 && p->wblur_presplit) {
@@ -1921,14 +1944,17 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
         if (mode[1] == 'h') {            // "1h": two-piece fp16 producer/consumer kernel
             unsigned short *dB16 = nullptr;
             unsigned *dmax = nullptr;
-            float amA = 0.f, amB = 0.f;
-            for (size_t i = 0; i < (size_t)M * K; ++i) amA = std::max(amA, std::fabs(A[i]));
+            float amB = 0.f;
             for (float v : bt) amB = std::max(amB, std::fabs(v));
-            unsigned slots[64] = {0};
-            memcpy(&slots[5], &amA, 4);
+            std::vector<unsigned> rows((size_t)M, 0u);           // max |A[m][:]| as bit patterns
+            for (int m = 0; m < M; ++m) {
+                float am = 0.f;
+                for (int k = 0; k < K; ++k) am = std::max(am, std::fabs(A[(size_t)m * K + k]));
+                memcpy(&rows[m], &am, 4);
+            }
             HIP_OK(hipMalloc((void **)&dB16, bt.size() * 4));
-            HIP_OK(hipMalloc((void **)&dmax, sizeof(slots)));
-            HIP_OK(hipMemcpy(dmax, slots, sizeof(slots), hipMemcpyHostToDevice));
+            HIP_OK(hipMalloc((void **)&dmax, rows.size() * sizeof(unsigned)));
+            HIP_OK(hipMemcpy(dmax, rows.data(), rows.size() * sizeof(unsigned), hipMemcpyHostToDevice));
             g.sB16 = gemm_f16x2_scale(amB); g.B16 = dB16; g.pB16 = (long)bt.size(); g.amax = dmax;
             rc = launch_split2h(nullptr, dB, dB16, (long)bt.size(), (long)bt.size(), g.sB16);
             if (rc == 0) rc = launch_gemm_nt_f16x2_pc(nullptr, g);

@@ -116,6 +116,14 @@ def test_gemm_two_piece_fp16_selftest():
         bias = float(np.mean((Cg - ref) / ref))
         note("gemm_f16x2_pc_nonneg", err=rel(Cg, ref), bias=bias)
         assert rel(Cg, ref) < 1e-6 and abs(bias) < 3e-7          # one 4096-long fp32 accumulation chain (bf16 split: -8e-6 at 3072)
+        # one scale per row of the data operand: a hot row (1e8 x the others) does not cost the faint rows their precision
+        Ah = A.copy()
+        Ah[7] *= np.float32(1e8)
+        _lib.check(L.surfh_gemm_selftest(0, M, N, K, 1, _lib.fptr(Ah), _lib.fptr(B), _lib.fptr(Cg)))
+        refh = Ah.astype(np.float64) @ B.astype(np.float64)
+        per_row = np.linalg.norm(Cg - refh, axis=1) / np.linalg.norm(refh, axis=1)
+        note("gemm_f16x2_pc_hot_row", worst_row=float(per_row.max()))
+        assert per_row.max() < 1e-6
         Z = np.zeros((M, K), dtype=np.float32)
         _lib.check(L.surfh_gemm_selftest(0, M, N, K, 1, _lib.fptr(Z), _lib.fptr(B), _lib.fptr(Cg)))
         assert not Cg.any()

@@ -32,16 +32,19 @@ int run(int M, int N, int K, int sk, const char *name, bool check) {
     CK(hipStreamSynchronize(st));
     // two-piece fp16 operands: B split once with its power-of-two scale, A's maximum in the 64 slots its producer would fill
     unsigned short *dB16; unsigned *dmax;
-    CK(hipMalloc(&dB16, B.size() * 4)); CK(hipMalloc(&dmax, 64 * 4));
-    float amaxA = 0.f, amaxB = 0.f;
-    for (auto v : A) amaxA = std::max(amaxA, std::fabs(v));
+    CK(hipMalloc(&dB16, B.size() * 4)); CK(hipMalloc(&dmax, (size_t)M * 4));
+    float amaxB = 0.f;
     for (auto v : B) amaxB = std::max(amaxB, std::fabs(v));
     const float sB = gemm_f16x2_scale(amaxB);
     if (launch_split2h(st, dB, dB16, (long)B.size(), (long)B.size(), sB)) { printf("split2h failed\n"); return 1; }
     {
-        unsigned slots[64] = {0};
-        memcpy(&slots[17], &amaxA, 4);
-        CK(hipMemcpy(dmax, slots, sizeof(slots), hipMemcpyHostToDevice));
+        std::vector<unsigned> rows((size_t)M, 0u);            // max |A[m][:]| per row, as bit patterns
+        for (int m = 0; m < M; ++m) {
+            float am = 0.f;
+            for (int k = 0; k < K; ++k) am = std::max(am, std::fabs(A[(size_t)m * K + k]));
+            memcpy(&rows[m], &am, 4);
+        }
+        CK(hipMemcpy(dmax, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
     }
     CK(hipStreamSynchronize(st));
     const char *names[5] = {"shipped", "prod/cons", "pc B-pre", "pc AB-pre", "pc f16x2"};
