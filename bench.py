@@ -192,7 +192,10 @@ def main():
                     return "gemm_f32_kernel<128, 128>"
                 if os.environ.get("SURFH_WBLUR_PC") == "0":
                     return "gemm_nt_bf16x3_kernel"
-                return "gemm_nt_f16x2_pc_kernel" if os.environ.get("SURFH_WBLUR_F16") != "0" else "gemm_nt_bf16x3_pc_kernel"
+                if os.environ.get("SURFH_WBLUR_F16") == "0":
+                    return "gemm_nt_bf16x3_pc_kernel"
+                cc = os.environ.get("SURFH_WBLUR_CC", "2")
+                return "gemm_nt_f16x2_cc_kernel" if (cc == "2" or (cc == "1" and name.endswith("adj"))) else "gemm_nt_f16x2_pc_kernel"
             if name.startswith("dft_rx3_"):
                 return "dft_rx3_kernel"            # four template instances <KIND, MIX> of one kernel (dft_rx3.hip)
             if name.startswith("dft_fold_cols"):

@@ -33,6 +33,10 @@ struct GemmArgs {
     long pB16 = 0;
     float sB16 = 0.f;
     const unsigned *amax = nullptr;
+    // all-consumer kernel, alternative to amax: A's pieces carry one scale per (row, K segment) -- bscale[segment][M] with
+    // segment(k) = (k / segLinP) * segChunks + (k % segLinP) / 1024 (what launch_spmm_rows_f16 writes)
+    const float *bscale = nullptr;
+    int segLinP = 0, segChunks = 0;
 };
 
 // returns hipError_t as int; name is used by the profiler
@@ -54,3 +58,7 @@ int launch_gemm_nt_f16x2_pc(hipStream_t stream, const GemmArgs &g);
 // dst2[q*plane + i] = fp16 piece q (h, l) of src[i] / scale (round to nearest); scale from gemm_f16x2_scale(max |src|)
 int launch_split2h(hipStream_t stream, const float *src, unsigned short *dst2, long n, long plane, float scale);
 float gemm_f16x2_scale(float amax);
+// All-consumer form (gemm_cc16.hip): 256 x 256 tile, eight consumer waves, both operands as fp16 pieces delivered by LDS-DMA.
+// A3 / pA3 = pieces of A split row by row with the scales of amax[M] (launch_split_rows2h); B16 / pB16 / sB16 as above.
+int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g);
+int launch_split_rows2h(hipStream_t stream, const float *src, const unsigned *rowmax, unsigned short *dst2, int rows, int ld, long plane);

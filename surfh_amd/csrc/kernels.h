@@ -45,6 +45,13 @@ int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *
                      unsigned *pmax = nullptr, const int *rowptr = nullptr, const int *idx = nullptr, unsigned *rowmax = nullptr,
                      int NP = 0);
 long spmm_rows_waves(const EllTable &t, int nlam);
+// the gather writing its [NP][K] output as two fp16 pieces dst16[q*plane + ...] of value / block scale; one power-of-two
+// scale per workgroup, i.e. per (row, segment) with segment = (column / LinP) * nchunk + (column % LinP) / 1024, nchunk =
+// ceil(LinP / 1024): bscale[segment][NP] (entries of segments the table never writes must be 1)
+int launch_spmm_rows_f16(hipStream_t s, const EllTable &t, const float *src, unsigned short *dst16, long plane, int nlam, float *bscale,
+                         int NP, long K, int LinP);
+int launch_dequant_f16x2(hipStream_t s, const unsigned short *src16, long plane, const float *bscale, float *dst, int NP, long K, int LinP,
+                         int nchunk);
 long spmm_rows_entry(const EllTable &t, int r, int chunk, int wave);
 long ymat_from_y_waves(int PS, int Ldet, int aout);
 

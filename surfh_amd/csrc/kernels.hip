@@ -318,6 +318,80 @@ __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float 
                         (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
+// The gather with its output written as the two fp16 pieces the all-consumer GEMM reads (gemm_cc16.hip).  The scale is
+// per workgroup, i.e. per (operand row, segment of <= 1024 wavelengths of one beta column): the workgroup's maximum is known
+// before anything is stored, so no second pass over the operand is needed, and the scale is finer than one per row.
+// bscale[seg][NP] receives the power of two; seg = (column offset / LinP) * nchunk + chunk.
+__device__ __forceinline__ float f16x2_block_scale(float amax) {       // as f16x2_scale_of in gemm_pc16.hip / gemm_cc16.hip
+    if (!(amax > 0.f)) return 1.f;
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127;
+    int sc = e - 13;
+    sc = sc < -126 ? -126 : (sc > 127 ? 127 : sc);
+    return __uint_as_float((unsigned)(sc + 127) << 23);
+}
+
+__global__ __launch_bounds__(TPB) void spmm_rows_f16_kernel(EllTable t, const float *__restrict__ src, unsigned short *__restrict__ dst16,
+                                                            long plane, int nlam, float *__restrict__ bscale, int NP, long K, int LinP,
+                                                            int nchunk) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int per = (t.R + 7) / 8;
+    const int r = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int l4 = (blockIdx.y * TPB + threadIdx.x) * 4;
+    if (r >= t.R) return;                                 // workgroup-uniform
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l4 < nlam) {
+        const int n = t.cnt[r];
+        const int64_t *col = t.col + (long)r * t.W;
+        const float *val = t.val + (long)r * t.W;
+        int e = 0;
+        for (; e + 4 <= n; e += 4) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+            const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
+            const float4 x2 = *reinterpret_cast<const float4 *>(src + col[e + 2] + l4);
+            const float4 x3 = *reinterpret_cast<const float4 *>(src + col[e + 3] + l4);
+            const float v0 = val[e], v1 = val[e + 1], v2 = val[e + 2], v3 = val[e + 3];
+            acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+            acc.x += v1 * x1.x; acc.y += v1 * x1.y; acc.z += v1 * x1.z; acc.w += v1 * x1.w;
+            acc.x += v2 * x2.x; acc.y += v2 * x2.y; acc.z += v2 * x2.z; acc.w += v2 * x2.w;
+            acc.x += v3 * x3.x; acc.y += v3 * x3.y; acc.z += v3 * x3.z; acc.w += v3 * x3.w;
+        }
+        for (; e < n; ++e) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+            const float v0 = val[e];
+            acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
+        }
+    }
+    // workgroup maximum -> power-of-two scale
+    float m = fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w)));
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sm[TPB / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    const float scale = f16x2_block_scale(m), inv = 1.f / scale;
+    const int64_t off = t.dst_off[r];
+    if (threadIdx.x == 0) bscale[((off % K) / LinP * nchunk + blockIdx.y) * (long)NP + off / K] = scale;
+    if (l4 < nlam) {
+        const float x0 = acc.x * inv, x1 = acc.y * inv, x2 = acc.z * inv, x3 = acc.w * inv;
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
+        f16x4 h = {h0, h1, h2, h3};
+        f16x4 l = {(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1), (_Float16)(x2 - (float)h2), (_Float16)(x3 - (float)h3)};
+        *reinterpret_cast<f16x4 *>(dst16 + off + l4) = h;
+        *reinterpret_cast<f16x4 *>(dst16 + plane + off + l4) = l;
+    }
+}
+
+// debugging: the block-scaled fp16 operand back as fp32 [NP][K]
+__global__ __launch_bounds__(TPB) void dequant_f16x2_kernel(const unsigned short *__restrict__ src16, long plane, const float *__restrict__ bscale,
+                                                            float *__restrict__ dst, int NP, long K, int LinP, int nchunk) {
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= (long)NP * K) return;
+    const long row = i / K, k = i % K;
+    const float sc = bscale[((k / LinP) * nchunk + (k % LinP) / 1024) * (long)NP + row];
+    const _Float16 h = reinterpret_cast<const _Float16 *>(src16)[i], l = reinterpret_cast<const _Float16 *>(src16)[plane + i];
+    dst[i] = ((float)h + (float)l) * sc;
+}
+
 // [L][na][nb] planes l0.. of a wavelength-major cube -> [nb][nap][LP] wavelength innermost (32x32 LDS tile transpose)
 __global__ __launch_bounds__(256) void cube_to_lam_inner_kernel(const float *__restrict__ src, float *__restrict__ dst,
                                                                 int l0, int L, int na, int nb, int nap, int LP) {
@@ -745,6 +819,23 @@ int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *
     hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate, pmax);
     if (pmax)
         hipLaunchKernelGGL(rowmax_csr_kernel, dim3((NP + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, pmax, rowptr, idx, NP, rowmax);
+    return (int)hipGetLastError();
+}
+
+int launch_spmm_rows_f16(hipStream_t s, const EllTable &t, const float *src, unsigned short *dst16, long plane, int nlam, float *bscale,
+                         int NP, long K, int LinP) {
+    if (t.R == 0 || nlam <= 0) return 0;
+    if (nlam % 4 || plane % 4 || K % LinP || LinP % 32 || !bscale) return (int)hipErrorInvalidValue;
+    dim3 grid((t.R + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(spmm_rows_f16_kernel, grid, dim3(TPB), 0, s, t, src, dst16, plane, nlam, bscale, NP, K, LinP, (LinP + 1023) / 1024);
+    return (int)hipGetLastError();
+}
+
+int launch_dequant_f16x2(hipStream_t s, const unsigned short *src16, long plane, const float *bscale, float *dst, int NP, long K, int LinP,
+                         int nchunk) {
+    const long n = (long)NP * K;
+    hipLaunchKernelGGL(dequant_f16x2_kernel, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, src16, plane, bscale, dst, NP, K, LinP,
+                       nchunk);
     return (int)hipGetLastError();
 }
 

@@ -84,6 +84,8 @@ struct Channel {
     float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
     unsigned short *W3 = nullptr, *Wt3 = nullptr;   // the two constant GEMM operands cut once into their bf16 pieces [3][rows][cols]
     unsigned short *W16 = nullptr, *Wt16 = nullptr; // ... or into their two fp16 pieces [2][rows][cols] of W / sW (gemm_pc16.hip)
+    unsigned short *Xs16 = nullptr, *ymat16 = nullptr;   // the data operands as fp16 pieces (all-consumer kernel, gemm_cc16.hip)
+    float *bscale = nullptr;                        // Xs16's scales, one per (row, K segment): [nbs * ceil(LinP/1024)][NP]
     float sW = 1.f;
     unsigned *amax = nullptr;                       // [2][NP] max |row| of the data operands: Xs (forward), ymat (adjoint)
     unsigned *pmax = nullptr;                       // per-wave maxima of the kernel that wrote the operand (reduced into amax)
@@ -135,6 +137,7 @@ struct surfh_plan {
     bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
     bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
     bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
+    int wblur_cc = 2;                            // all-consumer 256 x 256 GEMM (gemm_cc16.hip): 0 off, 1 adjoint only, 2 both directions
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
@@ -463,7 +466,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     return 0;
 }
 
-int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu, int max_steps = 34) {
+int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu, int max_steps = 34, int tile_m = 128, int tile_n = 256) {
     if (forced > 0) return (c.K % (32 * forced) == 0) ? forced : 1;
     if (pc_kernel) {
         // producer/consumer kernel (128 x 256 tiles, one workgroup per CU).  The slab length is set by accuracy first:
@@ -472,7 +475,7 @@ int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu, int max_s
         // round of workgroups best.  The two-piece fp16 products have no small terms to lose: measured bias on non-negative
         // operands -1.3e-7 for one 4096-long chain (plain fp32 accumulation), so they run chains of up to 4352 k
         // (max_steps 136): a quarter of the slabs to sum.
-        const long tiles = (long)(c.NP / 128) * ((c.LdetP + 255) / 256);
+        const long tiles = (long)((c.NP + tile_m - 1) / tile_m) * ((c.LdetP + tile_n - 1) / tile_n);
         const int steps = c.K / 32;
         int smin = 0;
         for (int s = 1; s <= steps; ++s)
@@ -480,7 +483,10 @@ int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu, int max_s
         if (!smin) return 1;
         int best = smin;
         double best_t = -1.0;
-        for (int s = smin; s <= smin + smin / 2 && s <= steps; ++s) {
+        // bf16 form: up to 1.5x the minimum (its chains should stay long enough to amortise the slab sum); the fp16 forms
+        // (max_steps > 34) may cut much finer to fill the CUs: any divisor leaving at least 16 K steps per slab
+        const int smax = max_steps > 34 ? steps / 16 : smin + smin / 2;
+        for (int s = smin; s <= smax && s <= steps; ++s) {
             if (steps % s) continue;
             const double t = (double)((tiles * s + n_cu - 1) / n_cu) * (steps / s) + 3.0 * s;
             if (best_t < 0 || t < best_t) { best_t = t; best = s; }
@@ -827,8 +833,11 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
         const bool f16 = c.W16 != nullptr;
         {
             Prof pr(p, "spmm_gather_fwd");
-            LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, c.rm_ptr, c.rm_idx,
-                                       f16 ? c.amax : nullptr, c.NP));
+            if (c.Xs16)     // straight to the block-scaled fp16 pieces of the all-consumer GEMM
+                LAUNCH_OK(launch_spmm_rows_f16(s, c.fwd.t, p->cube, c.Xs16, (long)c.NP * c.K, c.nlam, c.bscale, c.NP, c.K, c.LinP));
+            else
+                LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, c.rm_ptr, c.rm_idx,
+                                           f16 ? c.amax : nullptr, c.NP));
         }
         if (c.bsum) {   // y[l][(p,s,a)] = Xs[(p,s,a)][l]
             Prof pr(p, "y_transpose");
@@ -849,6 +858,11 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
                 g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
                 g.B3 = c.W3; g.pB3 = (long)c.LdetP * c.K;
                 g.B16 = c.W16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
+                if (f16 && c.Xs16) {       // both operands as pieces: 256 x 256 all-consumer kernel
+                    g.A3 = c.Xs16; g.pA3 = (long)c.NP * c.K;
+                    g.amax = nullptr; g.bscale = c.bscale; g.segLinP = c.LinP; g.segChunks = (c.LinP + 1023) / 1024;
+                    LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
+                } else
                 LAUNCH_OK(f16 ? launch_gemm_nt_f16x2_pc(sB, g) : p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
@@ -902,6 +916,11 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
                 g.B3 = c.Wt3; g.pB3 = (long)c.LdetP * c.K;
                 g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax + c.NP;
+                if (f16 && c.ymat16) {
+                    LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax + c.NP, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));
+                    g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
+                    LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
+                } else
                 LAUNCH_OK(f16 ? launch_gemm_nt_f16x2_pc(sB, g) : p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
             }
         }
@@ -974,6 +993,9 @@ int surfh_plan_destroy(surfh_plan *p) {
         hipFree(c.Wt3);
         hipFree(c.W16);
         hipFree(c.Wt16);
+        hipFree(c.Xs16);
+        hipFree(c.bscale);
+        hipFree(c.ymat16);
         hipFree(c.amax);
         hipFree(c.pmax);
         hipFree(c.rm_ptr);
@@ -1124,6 +1146,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
+        const char *e13 = getenv("SURFH_WBLUR_CC");
+        if (e13 && e13[0] >= '0' && e13[0] <= '2') p->wblur_cc = e13[0] - '0';
         const char *e12 = getenv("SURFH_GATHER_SORTED");
         p->gather_sorted = !(e12 && e12[0] == '0');   // 0: gather rows in (pointing, alpha, beta) order
         const char *e11 = getenv("SURFH_WBLUR_F16");
@@ -1210,8 +1234,9 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         c.yoff = yoff;
         yoff += c.ysize;
         if (c.bsum) continue;
-        c.splitK = pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu,
-                              (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) ? 136 : 34);
+        const bool f16 = p->wblur_pc && !p->wblur_fp32 && p->wblur_f16;
+        c.splitK = pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu, f16 ? 136 : 34,
+                              (f16 && p->wblur_cc == 2) ? 256 : 128, 256);
         if (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) {
             const long nw = (long)c.LdetP * c.K;
             c.pmax_adj = spmm_rows_waves(c.fwd.t, c.nlam);
@@ -1238,6 +1263,13 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                 return bail(1);
             hipMemset(c.pmax, 0, (size_t)nwv * sizeof(unsigned));       // entries of workgroups that exit early stay 0
             hipMemset(c.amax, 0, (size_t)2 * c.NP * sizeof(unsigned));
+            if (p->wblur_cc >= 1 && dev_alloc(&c.ymat16, (size_t)2 * c.NP * c.LdetP)) return bail(1);
+            if (p->wblur_cc == 2) {
+                if (dev_alloc(&c.Xs16, (size_t)2 * c.NP * c.K)) return bail(1);
+                hipMemset(c.Xs16, 0, (size_t)2 * c.NP * c.K * sizeof(unsigned short));       // padding rows / columns stay zero
+                std::vector<float> ones((size_t)c.nbs * ((c.LinP + 1023) / 1024) * c.NP, 1.f);   // segments never written: scale 1
+                if (dev_upload(&c.bscale, ones)) return bail(1);
+            }
             if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
                 return bail(fail("operand split failed"));
         } else if (p->wblur_pc && !p->wblur_fp32 && p->wblur_presplit) {
@@ -1887,6 +1919,13 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
         if (info) {                                 // (LinP, first valid lambda column, n_beta_slit, Lin)
             dims[0] = p->ch[c].LinP; dims[1] = p->ch[c].shift; dims[2] = p->ch[c].nbs; dims[3] = p->ch[c].Lin;
         } else {                                    // [(p,s,a)][b'][LinP]
+            Channel &ch = p->ch[c];
+            if (ch.Xs16) {     // the forward operand lives as block-scaled fp16 pieces: rebuilt in fp32 for inspection
+                if (launch_dequant_f16x2(p->stream, ch.Xs16, (long)ch.NP * ch.K, ch.bscale, ch.Xs, ch.NP, ch.K, ch.LinP,
+                                         (ch.LinP + 1023) / 1024))
+                    return fail("dequant launch failed");
+                if (hipStreamSynchronize(p->stream) != hipSuccess) return fail("dequant failed");
+            }
             *ptr = p->ch[c].Xs; dims[0] = p->ch[c].NP; dims[1] = p->ch[c].bsum ? 1 : p->ch[c].nbs; dims[2] = p->ch[c].LinP;
         }
     } else if (w == "info") {

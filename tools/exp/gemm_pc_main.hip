@@ -47,14 +47,21 @@ int run(int M, int N, int K, int sk, const char *name, bool check) {
         CK(hipMemcpy(dmax, rows.data(), rows.size() * 4, hipMemcpyHostToDevice));
     }
     CK(hipStreamSynchronize(st));
-    const char *names[5] = {"shipped", "prod/cons", "pc B-pre", "pc AB-pre", "pc f16x2"};
-    for (int which = 0; which < 5; ++which) {
+    // all-consumer experiment kernel: A pre-split too, one scale for the whole operand
+    unsigned short *dA16;
+    CK(hipMalloc(&dA16, A.size() * 4));
+    if (launch_split_rows2h(st, dA, dmax, dA16, M, K, (long)A.size())) { printf("split_rows2h failed\n"); return 1; }
+    CK(hipStreamSynchronize(st));
+    const char *names[6] = {"shipped", "prod/cons", "pc B-pre", "pc AB-pre", "pc f16x2", "cc f16x2"};
+    for (int which = 0; which < 6; ++which) {
+        if (which == 5 && M % 64) continue;
         if (which == 0 && N % 128) continue;
         GemmArgs gg = g;
         if (which == 2 || which == 3) { gg.B3 = dB3; gg.pB3 = (long)B.size(); }
         if (which == 3) { gg.A3 = dA3; gg.pA3 = (long)A.size(); }
-        if (which == 4) { gg.B16 = dB16; gg.pB16 = (long)B.size(); gg.sB16 = sB; gg.amax = dmax; }
-        auto launch = [&]() { return which == 4 ? launch_gemm_nt_f16x2_pc(st, gg) : which ? launch_gemm_nt_bf16x3_pc(st, gg) : launch_gemm_nt_bf16x3(st, gg); };
+        if (which >= 4) { gg.B16 = dB16; gg.pB16 = (long)B.size(); gg.sB16 = sB; gg.amax = dmax; }
+        if (which == 5) { gg.A3 = dA16; gg.pA3 = (long)A.size(); }
+        auto launch = [&]() { return which == 5 ? launch_gemm_nt_f16x2_cc(st, gg) : which == 4 ? launch_gemm_nt_f16x2_pc(st, gg) : which ? launch_gemm_nt_bf16x3_pc(st, gg) : launch_gemm_nt_bf16x3(st, gg); };
         CK(hipMemset(dC, 0xFF, (size_t)nslab * M * N * 4));
         int rc = launch();
         if (rc) { printf("launch rc %d\n", rc); return 1; }
@@ -80,7 +87,7 @@ int run(int M, int N, int K, int sk, const char *name, bool check) {
         printf("%-8s %-9s M=%d N=%d K=%d sk=%d  rel L2 err %.3g   %.4f ms  %.1f TF/s fp32-equivalent\n", name, names[which], M, N, K, sk,
                check ? std::sqrt(num / den) : -1.0, ms, 2.0 * M * N * K / ms * 1e-9);
     }
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dA3); hipFree(dB3); hipFree(dB16); hipFree(dmax);
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dA3); hipFree(dB3); hipFree(dB16); hipFree(dmax); hipFree(dA16);
     return 0;
 }
 
