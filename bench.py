@@ -203,7 +203,9 @@ def main():
             if name.startswith("dft_fold_rows"):
                 return "dft_fold_kernel"
             if name.startswith("spmm_"):
-                return "spmm_rows_kernel"
+                f16 = os.environ.get("SURFH_WBLUR_F16") != "0" and os.environ.get("SURFH_WBLUR_PC") != "0" and \
+                    os.environ.get("SURFH_WBLUR_FP32") != "1" and os.environ.get("SURFH_WBLUR_CC", "2") == "2"
+                return "spmm_rows_f16_kernel" if (f16 and name == "spmm_gather_fwd") else "spmm_rows_kernel"
             if name.startswith("gemm_dft_") and name.endswith("_maps"):
                 return "gemm_f32_kernel<64, 64>"
             return name + "_kernel"
