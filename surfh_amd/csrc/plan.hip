@@ -1980,7 +1980,7 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
             for (int n = 0; n < N; ++n) bt[(size_t)n * K + k] = B[(size_t)k * N + n];
         HIP_OK(hipMemcpy(dB, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
         g.ldb = K;
-        if (mode[1] == 'h') {            // "1h": two-piece fp16 producer/consumer kernel
+        if (mode[1] == 'h' || mode[1] == 'c') {            // "1h": two-piece fp16 producer/consumer kernel, "1c": all-consumer kernel
             unsigned short *dB16 = nullptr;
             unsigned *dmax = nullptr;
             float amB = 0.f;
@@ -1996,10 +1996,19 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
             HIP_OK(hipMemcpy(dmax, rows.data(), rows.size() * sizeof(unsigned), hipMemcpyHostToDevice));
             g.sB16 = gemm_f16x2_scale(amB); g.B16 = dB16; g.pB16 = (long)bt.size(); g.amax = dmax;
             rc = launch_split2h(nullptr, dB, dB16, (long)bt.size(), (long)bt.size(), g.sB16);
-            if (rc == 0) rc = launch_gemm_nt_f16x2_pc(nullptr, g);
+            unsigned short *dA16 = nullptr;
+            if (rc == 0 && mode[1] == 'c') {
+                HIP_OK(hipMalloc((void **)&dA16, (size_t)M * K * 4));
+                rc = launch_split_rows2h(nullptr, dA, dmax, dA16, M, K, (long)M * K);
+                g.A3 = dA16; g.pA3 = (long)M * K;
+                if (rc == 0) rc = launch_gemm_nt_f16x2_cc(nullptr, g);
+            } else if (rc == 0) {
+                rc = launch_gemm_nt_f16x2_pc(nullptr, g);
+            }
             if (rc == 0) rc = (int)hipDeviceSynchronize();
             hipFree(dB16);
             hipFree(dmax);
+            hipFree(dA16);
         } else
         rc = (mode[1] == 'p') ? launch_gemm_nt_bf16x3_pc(nullptr, g) : launch_gemm_nt_bf16x3(nullptr, g);   // "1p": producer/consumer kernel
     } else {

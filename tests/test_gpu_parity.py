@@ -87,17 +87,18 @@ def test_gemm_producer_consumer_selftest():
         os.environ.pop("SURFH_SELFTEST_BF16X3")
 
 
-def test_gemm_two_piece_fp16_selftest():
-    """The two-piece fp16 producer/consumer GEMM (gemm_pc16.hip): power-of-two operand scales, round-to-nearest split,
-    three products.  Same gate as the bf16 split; element magnitudes spread over 12 decades within the operand (entries far
+@pytest.mark.parametrize("kernel", ["1h", "1c"], ids=["producer_consumer", "all_consumer_256"])
+def test_gemm_two_piece_fp16_selftest(kernel):
+    """The two-piece fp16 GEMMs (gemm_pc16.hip; gemm_cc16.hip, the 256x256 all-consumer tile with both operands delivered
+    as pieces by LDS-DMA): power-of-two operand scales, round-to-nearest split, three products.  Same gate as the bf16 split; element magnitudes spread over 12 decades within the operand (entries far
     below the operand's largest magnitude keep their absolute, not their relative, precision), an all-zero operand, and
     non-negative operands where a truncating split would show a bias."""
     from surfh_amd import _lib
     L = _lib.load()
     rng = np.random.default_rng(2)
-    os.environ["SURFH_SELFTEST_BF16X3"] = "1h"
+    os.environ["SURFH_SELFTEST_BF16X3"] = kernel
     try:
-        for (M, N, K, sk) in [(128, 128, 32, 1), (128, 256, 64, 1), (256, 384, 512, 2), (384, 640, 1056, 3)]:
+        for (M, N, K, sk) in [(128, 128, 32, 1), (128, 256, 64, 1), (256, 384, 512, 2), (384, 640, 1056, 3), (1664, 1408, 2112, 2)]:
             A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, K)))).astype(np.float32)
             B = rng.standard_normal((K, N)).astype(np.float32) + np.arange(N, dtype=np.float32)[None, :] * 0.02
             for scale in (1.0, 1e20, 1e-20):
