@@ -41,6 +41,20 @@ struct EllTable {
 // [spmm_rows_waves()]; a second pass takes, for every row of the [NP][K] operand the table writes, the maximum over the
 // entries listed in rowptr / idx (built once with spmm_rows_entry) -- the per-row scales of the data operand of the
 // two-piece fp16 GEMM (gemm_pc16.hip)
+// Scatter table with its rows taken SCATTER_G at a time: neighbouring cube pixels receive from almost the same operand
+// rows, so a group reads the union of its members' taps once and applies one weight per member (0 where a member does not
+// use the tap).  dst < 0 marks a missing member.
+constexpr int SCATTER_G = 4;
+struct GroupTable {
+    int NG = 0, W = 0;                 // groups, max union taps per group
+    const int32_t *cnt = nullptr;      // [NG]
+    const int64_t *col = nullptr;      // [NG][W]
+    const float *val = nullptr;        // [NG][W][SCATTER_G]
+    const int64_t *dst = nullptr;      // [NG][SCATTER_G]
+    const uint32_t *rmw = nullptr;     // [NG][SCATTER_G] read-modify-write chunk masks (as EllTable::rmw)
+};
+int launch_spmm_group_scatter(hipStream_t s, const GroupTable &t, const float *src, float *dst, int nlam);
+
 int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate,
                      unsigned *pmax = nullptr, const int *rowptr = nullptr, const int *idx = nullptr, unsigned *rowmax = nullptr,
                      int NP = 0);

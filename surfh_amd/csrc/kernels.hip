@@ -318,6 +318,52 @@ __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float 
                         (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
+// grouped scatter: one workgroup = SCATTER_G neighbouring cube pixels x 1024 wavelengths (see GroupTable)
+__global__ __launch_bounds__(TPB) void spmm_group_scatter_kernel(GroupTable t, const float *__restrict__ src, float *__restrict__ dst,
+                                                                 int nlam) {
+    const int per = (t.NG + 7) / 8;
+    const int gi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int l4 = (blockIdx.y * TPB + threadIdx.x) * 4;
+    if (gi >= t.NG || l4 >= nlam) return;
+    const int n = t.cnt[gi];
+    const int64_t *col = t.col + (long)gi * t.W;
+    const float *val = t.val + (long)gi * t.W * SCATTER_G;
+    float4 acc[SCATTER_G];
+#pragma unroll
+    for (int g = 0; g < SCATTER_G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int e = 0;
+    for (; e + 2 <= n; e += 2) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+        const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
+#pragma unroll
+        for (int g = 0; g < SCATTER_G; ++g) {
+            const float v0 = val[e * SCATTER_G + g], v1 = val[(e + 1) * SCATTER_G + g];
+            acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
+            acc[g].x += v1 * x1.x; acc[g].y += v1 * x1.y; acc[g].z += v1 * x1.z; acc[g].w += v1 * x1.w;
+        }
+    }
+    for (; e < n; ++e) {
+        const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+#pragma unroll
+        for (int g = 0; g < SCATTER_G; ++g) {
+            const float v0 = val[e * SCATTER_G + g];
+            acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < SCATTER_G; ++g) {
+        const int64_t d = t.dst[(long)gi * SCATTER_G + g];
+        if (d < 0) continue;                               // workgroup-uniform
+        float4 *p = reinterpret_cast<float4 *>(dst + d + l4);
+        float4 a = acc[g];
+        if ((t.rmw[(long)gi * SCATTER_G + g] >> blockIdx.y) & 1u) {
+            const float4 o = *p;
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        *p = a;
+    }
+}
+
 // The gather with its output written as the two fp16 pieces the all-consumer GEMM reads (gemm_cc16.hip).  The scale is
 // per workgroup, i.e. per (operand row, segment of <= 1024 wavelengths of one beta column): the workgroup's maximum is known
 // before anything is stored, so no second pass over the operand is needed, and the scale is finer than one per row.
@@ -819,6 +865,14 @@ int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *
     hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate, pmax);
     if (pmax)
         hipLaunchKernelGGL(rowmax_csr_kernel, dim3((NP + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, pmax, rowptr, idx, NP, rowmax);
+    return (int)hipGetLastError();
+}
+
+int launch_spmm_group_scatter(hipStream_t s, const GroupTable &t, const float *src, float *dst, int nlam) {
+    if (t.NG == 0 || nlam <= 0) return 0;
+    if (nlam % 4 || (nlam / 4 + TPB - 1) / TPB > 32) return (int)hipErrorInvalidValue;
+    dim3 grid((t.NG + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(spmm_group_scatter_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam);
     return (int)hipGetLastError();
 }
 

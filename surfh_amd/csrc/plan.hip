@@ -21,6 +21,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -62,6 +63,12 @@ int fail(const char *fmt, ...) {
 
 inline int pad64(int n) { return (n + 63) / 64 * 64; }
 
+// host-side sparse rows: (source index, weight) lists + one destination per row
+struct HostEll {
+    std::vector<std::vector<std::pair<int64_t, float>>> rows;
+    std::vector<int64_t> dst;
+};
+
 struct DevEll {
     EllTable t;
     int32_t *cnt = nullptr;
@@ -69,6 +76,12 @@ struct DevEll {
     float *val = nullptr;
     uint32_t *rmw = nullptr;            // scatter tables: chunks of a row that need read-modify-write (EllTable::rmw)
     std::vector<int64_t> host_dst;      // kept for the scatter tables until the plan is complete
+    // the same table with its rows grouped SCATTER_G at a time (GroupTable)
+    GroupTable g;
+    int32_t *g_cnt = nullptr;
+    int64_t *g_col = nullptr, *g_dst = nullptr;
+    float *g_val = nullptr;
+    uint32_t *g_rmw = nullptr;
 };
 
 struct Channel {
@@ -93,6 +106,7 @@ struct Channel {
     int *rm_ptr = nullptr, *rm_idx = nullptr;       // forward: pmax entries of every GEMM row (CSR)
     std::vector<int64_t> fwd_dst;                   // destinations of the gather rows, kept until the CSR is built
     DevEll fwd, adjT, adjRef;
+    HostEll adjT_host;                  // kept until the grouped scatter table is built (plan creation)
     bool has_ref = false;
     bool bsum = false;   // no spectral blur: y[l][(p,s,a)] = sum over the slit's beta columns (MRSBlurred)
 };
@@ -137,6 +151,7 @@ struct surfh_plan {
     bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
     bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
     bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
+    bool scatter_grouped = true;                 // adjoint scatter with SCATTER_G neighbouring pixels per workgroup (GroupTable)
     int wblur_cc = 2;                            // all-consumer 256 x 256 GEMM (gemm_cc16.hip): 0 off, 1 adjoint only, 2 both directions
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
@@ -230,11 +245,6 @@ int dev_upload(Tp **p, const std::vector<Tp> &h) {
     return 0;
 }
 
-// host-side sparse rows: (source index, weight) lists + one destination per row
-struct HostEll {
-    std::vector<std::vector<std::pair<int64_t, float>>> rows;
-    std::vector<int64_t> dst;
-};
 
 int upload_ell(const HostEll &h, DevEll *d) {
     const int R = (int)h.rows.size();
@@ -262,6 +272,11 @@ int upload_ell(const HostEll &h, DevEll *d) {
 }
 
 void free_ell(DevEll *d) {
+    hipFree(d->g_cnt);
+    hipFree(d->g_col);
+    hipFree(d->g_dst);
+    hipFree(d->g_val);
+    hipFree(d->g_rmw);
     hipFree(d->rmw);
     hipFree(d->cnt);
     hipFree(d->col);
@@ -404,6 +419,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
         }
         if (upload_ell(t, &c->adjT)) return 1;
         c->adjT.host_dst = t.dst;
+        c->adjT_host = std::move(t);
     }
 
     // ---- reference-compatible back-interpolation (gridding_t) ---------------------------------
@@ -894,7 +910,10 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
                 LAUNCH_OK(launch_cube_to_lam_inner(s, y + c.yoff, c.Xs + c.shift, 0, c.Lin, 1, c.P * c.S * c.aout, 1, c.LinP));
             }
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
-            LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+            if (!ref && c.adjT.g.NG)
+                LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, p->cube, c.nlam));
+            else
+                LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
             continue;
         }
         const bool f16 = c.W16 != nullptr;
@@ -927,7 +946,10 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
         if (chain(p, sB, s)) return 1;
         {
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
-            LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+            if (!ref && c.adjT.g.NG)
+                LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, p->cube, c.nlam));
+            else
+                LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
         }
     }
     if (rfft2_cube(p, p->cube, p->spec)) return 1;
@@ -1146,6 +1168,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
+        const char *e14 = getenv("SURFH_SCATTER_GROUPED");
+        p->scatter_grouped = !(e14 && e14[0] == '0');
         const char *e13 = getenv("SURFH_WBLUR_CC");
         if (e13 && e13[0] >= '0' && e13[0] <= '2') p->wblur_cc = e13[0] - '0';
         const char *e12 = getenv("SURFH_GATHER_SORTED");
@@ -1307,6 +1331,56 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                     }
                 }
             }
+            {
+                const char *ea0 = getenv("SURFH_SCATTER_RMW_ALL");
+                if (ea0 && ea0[0] == '1') std::fill(mask.begin(), mask.end(), 0xFFFFFFFFu);
+            }
+            if (p->scatter_grouped) {
+                // rows are in pixel order: take runs of neighbouring pixels (destinations LP apart), SCATTER_G at a time
+                const HostEll &h = c.adjT_host;
+                std::vector<int32_t> gcnt;
+                std::vector<std::vector<std::pair<int64_t, std::array<float, SCATTER_G>>>> grows;
+                std::vector<int64_t> gdst;
+                std::vector<uint32_t> grmw;
+                size_t r = 0;
+                while (r < h.rows.size()) {
+                    size_t n = 1;
+                    while (n < (size_t)SCATTER_G && r + n < h.rows.size() && h.dst[r + n] == h.dst[r + n - 1] + p->LP) ++n;
+                    std::map<int64_t, std::array<float, SCATTER_G>> u;
+                    for (size_t m = 0; m < n; ++m)
+                        for (auto &e : h.rows[r + m]) {
+                            auto it = u.find(e.first);
+                            if (it == u.end()) it = u.emplace(e.first, std::array<float, SCATTER_G>{}).first;
+                            it->second[m] += e.second;
+                        }
+                    std::vector<std::pair<int64_t, std::array<float, SCATTER_G>>> row(u.begin(), u.end());
+                    grows.push_back(std::move(row));
+                    for (size_t m = 0; m < (size_t)SCATTER_G; ++m) {
+                        gdst.push_back(m < n ? h.dst[r + m] : -1);
+                        grmw.push_back(m < n ? mask[r + m] : 0u);
+                    }
+                    r += n;
+                }
+                int W = 1;
+                for (auto &row : grows) W = std::max(W, (int)row.size());
+                const size_t NG = grows.size();
+                std::vector<int64_t> gcol(NG * W, 0);
+                std::vector<float> gval(NG * W * SCATTER_G, 0.f);
+                gcnt.resize(NG);
+                for (size_t gi = 0; gi < NG; ++gi) {
+                    gcnt[gi] = (int32_t)grows[gi].size();
+                    for (size_t e = 0; e < grows[gi].size(); ++e) {
+                        gcol[gi * W + e] = grows[gi][e].first;
+                        for (int m = 0; m < SCATTER_G; ++m) gval[(gi * W + e) * SCATTER_G + m] = grows[gi][e].second[m];
+                    }
+                }
+                DevEll &d = c.adjT;
+                if (dev_upload(&d.g_cnt, gcnt) || dev_upload(&d.g_col, gcol) || dev_upload(&d.g_val, gval) || dev_upload(&d.g_dst, gdst) ||
+                    dev_upload(&d.g_rmw, grmw))
+                    return bail(1);
+                d.g.NG = (int)NG; d.g.W = W; d.g.cnt = d.g_cnt; d.g.col = d.g_col; d.g.val = d.g_val; d.g.dst = d.g_dst; d.g.rmw = d.g_rmw;
+            }
+            c.adjT_host = HostEll();
             if (dev_upload(&c.adjT.rmw, mask)) return bail(1);
             const char *ea = getenv("SURFH_SCATTER_RMW_ALL");
             if (!(ea && ea[0] == '1')) c.adjT.t.rmw = c.adjT.rmw;        // 1: read-modify-write everywhere (A/B)
