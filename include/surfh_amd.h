@@ -24,7 +24,8 @@
  *     of the solvers accumulate in fp64.
  *   - environment switches read at plan creation (A/B paths, all parity-tested): SURFH_DFT_RX3=0,
  *     SURFH_FOLD2=1, SURFH_DFT_DENSE=1, SURFH_NO_FUSED_MIX=1, SURFH_DFT_PACKED=0, SURFH_WBLUR_FP32=1,
- *     SURFH_WBLUR_F16=0, SURFH_WBLUR_CC=0|1, SURFH_WBLUR_PC=0, SURFH_WBLUR_PRESPLIT=0, SURFH_GATHER_SORTED=0, SURFH_SCATTER_RMW_ALL=1,
+ *     SURFH_WBLUR_F16=0, SURFH_WBLUR_CC=0|1, SURFH_WBLUR_PC=0, SURFH_WBLUR_PRESPLIT=0, SURFH_GATHER_SORTED=0, SURFH_GATHER_GROUPED=0,
+ *     SURFH_SCATTER_GROUPED=0, SURFH_SCATTER_RMW_ALL=1,
  *     SURFH_OVERLAP=1.
  */
 #ifndef SURFH_AMD_H

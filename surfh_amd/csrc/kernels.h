@@ -54,6 +54,9 @@ struct GroupTable {
     const uint32_t *rmw = nullptr;     // [NG][SCATTER_G] read-modify-write chunk masks (as EllTable::rmw)
 };
 int launch_spmm_group_scatter(hipStream_t s, const GroupTable &t, const float *src, float *dst, int nlam);
+// the gather of launch_spmm_rows_f16 on a grouped table (members = rows neighbouring in cube-location order)
+int launch_spmm_group_gather_f16(hipStream_t s, const GroupTable &t, const float *src, unsigned short *dst16, long plane, int nlam,
+                                 float *bscale, int NP, long K, int LinP);
 
 int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate,
                      unsigned *pmax = nullptr, const int *rowptr = nullptr, const int *idx = nullptr, unsigned *rowmax = nullptr,

@@ -427,6 +427,67 @@ __global__ __launch_bounds__(TPB) void spmm_rows_f16_kernel(EllTable t, const fl
     }
 }
 
+// the same on a grouped table: the members' taps are read once; every member keeps its own block scale
+__global__ __launch_bounds__(TPB) void spmm_group_gather_f16_kernel(GroupTable t, const float *__restrict__ src,
+                                                                    unsigned short *__restrict__ dst16, long plane, int nlam,
+                                                                    float *__restrict__ bscale, int NP, long K, int LinP, int nchunk) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int per = (t.NG + 7) / 8;
+    const int gi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    const int l4 = (blockIdx.y * TPB + threadIdx.x) * 4;
+    if (gi >= t.NG) return;                               // workgroup-uniform
+    float4 acc[SCATTER_G];
+#pragma unroll
+    for (int g = 0; g < SCATTER_G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (l4 < nlam) {
+        const int n = t.cnt[gi];
+        const int64_t *col = t.col + (long)gi * t.W;
+        const float *val = t.val + (long)gi * t.W * SCATTER_G;
+        int e = 0;
+        for (; e + 2 <= n; e += 2) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+            const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
+#pragma unroll
+            for (int g = 0; g < SCATTER_G; ++g) {
+                const float v0 = val[e * SCATTER_G + g], v1 = val[(e + 1) * SCATTER_G + g];
+                acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
+                acc[g].x += v1 * x1.x; acc[g].y += v1 * x1.y; acc[g].z += v1 * x1.z; acc[g].w += v1 * x1.w;
+            }
+        }
+        for (; e < n; ++e) {
+            const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
+#pragma unroll
+            for (int g = 0; g < SCATTER_G; ++g) {
+                const float v0 = val[e * SCATTER_G + g];
+                acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
+            }
+        }
+    }
+    __shared__ float sm[SCATTER_G][TPB / 64];
+#pragma unroll
+    for (int g = 0; g < SCATTER_G; ++g) {
+        float m = fmaxf(fmaxf(fabsf(acc[g].x), fabsf(acc[g].y)), fmaxf(fabsf(acc[g].z), fabsf(acc[g].w)));
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if ((threadIdx.x & 63) == 0) sm[g][threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int g = 0; g < SCATTER_G; ++g) {
+        const int64_t off = t.dst[(long)gi * SCATTER_G + g];
+        if (off < 0) continue;                             // workgroup-uniform
+        const float scale = f16x2_block_scale(fmaxf(fmaxf(sm[g][0], sm[g][1]), fmaxf(sm[g][2], sm[g][3]))), inv = 1.f / scale;
+        if (threadIdx.x == 0) bscale[((off % K) / LinP * nchunk + blockIdx.y) * (long)NP + off / K] = scale;
+        if (l4 < nlam) {
+            const float x0 = acc[g].x * inv, x1 = acc[g].y * inv, x2 = acc[g].z * inv, x3 = acc[g].w * inv;
+            const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
+            f16x4 h = {h0, h1, h2, h3};
+            f16x4 l = {(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1), (_Float16)(x2 - (float)h2), (_Float16)(x3 - (float)h3)};
+            *reinterpret_cast<f16x4 *>(dst16 + off + l4) = h;
+            *reinterpret_cast<f16x4 *>(dst16 + plane + off + l4) = l;
+        }
+    }
+}
+
 // debugging: the block-scaled fp16 operand back as fp32 [NP][K]
 __global__ __launch_bounds__(TPB) void dequant_f16x2_kernel(const unsigned short *__restrict__ src16, long plane, const float *__restrict__ bscale,
                                                             float *__restrict__ dst, int NP, long K, int LinP, int nchunk) {
@@ -882,6 +943,16 @@ int launch_spmm_rows_f16(hipStream_t s, const EllTable &t, const float *src, uns
     if (nlam % 4 || plane % 4 || K % LinP || LinP % 32 || !bscale) return (int)hipErrorInvalidValue;
     dim3 grid((t.R + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
     hipLaunchKernelGGL(spmm_rows_f16_kernel, grid, dim3(TPB), 0, s, t, src, dst16, plane, nlam, bscale, NP, K, LinP, (LinP + 1023) / 1024);
+    return (int)hipGetLastError();
+}
+
+int launch_spmm_group_gather_f16(hipStream_t s, const GroupTable &t, const float *src, unsigned short *dst16, long plane, int nlam,
+                                 float *bscale, int NP, long K, int LinP) {
+    if (t.NG == 0 || nlam <= 0) return 0;
+    if (nlam % 4 || plane % 4 || K % LinP || LinP % 32 || !bscale) return (int)hipErrorInvalidValue;
+    dim3 grid((t.NG + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
+    hipLaunchKernelGGL(spmm_group_gather_f16_kernel, grid, dim3(TPB), 0, s, t, src, dst16, plane, nlam, bscale, NP, K, LinP,
+                       (LinP + 1023) / 1024);
     return (int)hipGetLastError();
 }
 

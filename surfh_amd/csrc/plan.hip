@@ -152,6 +152,7 @@ struct surfh_plan {
     bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
     bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
     bool scatter_grouped = true;                 // adjoint scatter with SCATTER_G neighbouring pixels per workgroup (GroupTable)
+    bool gather_grouped = true;                  // forward gather (fp16 output) likewise
     int wblur_cc = 2;                            // all-consumer 256 x 256 GEMM (gemm_cc16.hip): 0 off, 1 adjoint only, 2 both directions
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
@@ -284,6 +285,45 @@ void free_ell(DevEll *d) {
     hipFree(d->dst);
 }
 
+// rows [r, r + n) of h taken as one group: union of their taps with one weight per member
+int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>> &runs, const std::vector<uint32_t> *mask, DevEll *d) {
+    const size_t NG = runs.size();
+    std::vector<std::vector<std::pair<int64_t, std::array<float, SCATTER_G>>>> grows(NG);
+    std::vector<int64_t> gdst(NG * SCATTER_G, -1);
+    std::vector<uint32_t> grmw(NG * SCATTER_G, 0u);
+    int W = 1;
+    for (size_t gi = 0; gi < NG; ++gi) {
+        const size_t r = runs[gi].first, n = runs[gi].second;
+        std::map<int64_t, std::array<float, SCATTER_G>> u;
+        for (size_t m = 0; m < n; ++m) {
+            for (auto &e : h.rows[r + m]) {
+                auto it = u.find(e.first);
+                if (it == u.end()) it = u.emplace(e.first, std::array<float, SCATTER_G>{}).first;
+                it->second[m] += e.second;
+            }
+            gdst[gi * SCATTER_G + m] = h.dst[r + m];
+            if (mask) grmw[gi * SCATTER_G + m] = (*mask)[r + m];
+        }
+        grows[gi].assign(u.begin(), u.end());
+        W = std::max(W, (int)grows[gi].size());
+    }
+    std::vector<int32_t> gcnt(NG);
+    std::vector<int64_t> gcol(NG * W, 0);
+    std::vector<float> gval(NG * W * SCATTER_G, 0.f);
+    for (size_t gi = 0; gi < NG; ++gi) {
+        gcnt[gi] = (int32_t)grows[gi].size();
+        for (size_t e = 0; e < grows[gi].size(); ++e) {
+            gcol[gi * W + e] = grows[gi][e].first;
+            for (int m = 0; m < SCATTER_G; ++m) gval[(gi * W + e) * SCATTER_G + m] = grows[gi][e].second[m];
+        }
+    }
+    if (dev_upload(&d->g_cnt, gcnt) || dev_upload(&d->g_col, gcol) || dev_upload(&d->g_val, gval) || dev_upload(&d->g_dst, gdst) ||
+        dev_upload(&d->g_rmw, grmw))
+        return 1;
+    d->g.NG = (int)NG; d->g.W = W; d->g.cnt = d->g_cnt; d->g.col = d->g_col; d->g.val = d->g_val; d->g.dst = d->g_dst; d->g.rmw = d->g_rmw;
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------
 // table construction for one channel
 // ---------------------------------------------------------------------------------------------
@@ -404,6 +444,11 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     }
     if (upload_ell(f, &c->fwd)) return 1;
     c->fwd_dst = f.dst;
+    if (p->gather_grouped && p->gather_sorted && !c->bsum) {      // SCATTER_G rows neighbouring in cube-location order per workgroup
+        std::vector<std::pair<size_t, size_t>> runs;
+        for (size_t r = 0; r < f.rows.size(); r += SCATTER_G) runs.push_back({r, std::min<size_t>(SCATTER_G, f.rows.size() - r)});
+        if (upload_groups(f, runs, nullptr, &c->fwd)) return 1;
+    }
 
     // ---- exact transpose: rows = touched cube pixels ------------------------------------------
     {
@@ -849,7 +894,9 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
         const bool f16 = c.W16 != nullptr;
         {
             Prof pr(p, "spmm_gather_fwd");
-            if (c.Xs16)     // straight to the block-scaled fp16 pieces of the all-consumer GEMM
+            if (c.Xs16 && c.fwd.g.NG)     // straight to the block-scaled fp16 pieces of the all-consumer GEMM
+                LAUNCH_OK(launch_spmm_group_gather_f16(s, c.fwd.g, p->cube, c.Xs16, (long)c.NP * c.K, c.nlam, c.bscale, c.NP, c.K, c.LinP));
+            else if (c.Xs16)
                 LAUNCH_OK(launch_spmm_rows_f16(s, c.fwd.t, p->cube, c.Xs16, (long)c.NP * c.K, c.nlam, c.bscale, c.NP, c.K, c.LinP));
             else
                 LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, c.rm_ptr, c.rm_idx,
@@ -1168,6 +1215,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
         p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
+        const char *e15 = getenv("SURFH_GATHER_GROUPED");
+        p->gather_grouped = !(e15 && e15[0] == '0');
         const char *e14 = getenv("SURFH_SCATTER_GROUPED");
         p->scatter_grouped = !(e14 && e14[0] == '0');
         const char *e13 = getenv("SURFH_WBLUR_CC");
@@ -1338,47 +1387,14 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             if (p->scatter_grouped) {
                 // rows are in pixel order: take runs of neighbouring pixels (destinations LP apart), SCATTER_G at a time
                 const HostEll &h = c.adjT_host;
-                std::vector<int32_t> gcnt;
-                std::vector<std::vector<std::pair<int64_t, std::array<float, SCATTER_G>>>> grows;
-                std::vector<int64_t> gdst;
-                std::vector<uint32_t> grmw;
-                size_t r = 0;
-                while (r < h.rows.size()) {
+                std::vector<std::pair<size_t, size_t>> runs;
+                for (size_t r = 0; r < h.rows.size();) {
                     size_t n = 1;
                     while (n < (size_t)SCATTER_G && r + n < h.rows.size() && h.dst[r + n] == h.dst[r + n - 1] + p->LP) ++n;
-                    std::map<int64_t, std::array<float, SCATTER_G>> u;
-                    for (size_t m = 0; m < n; ++m)
-                        for (auto &e : h.rows[r + m]) {
-                            auto it = u.find(e.first);
-                            if (it == u.end()) it = u.emplace(e.first, std::array<float, SCATTER_G>{}).first;
-                            it->second[m] += e.second;
-                        }
-                    std::vector<std::pair<int64_t, std::array<float, SCATTER_G>>> row(u.begin(), u.end());
-                    grows.push_back(std::move(row));
-                    for (size_t m = 0; m < (size_t)SCATTER_G; ++m) {
-                        gdst.push_back(m < n ? h.dst[r + m] : -1);
-                        grmw.push_back(m < n ? mask[r + m] : 0u);
-                    }
+                    runs.push_back({r, n});
                     r += n;
                 }
-                int W = 1;
-                for (auto &row : grows) W = std::max(W, (int)row.size());
-                const size_t NG = grows.size();
-                std::vector<int64_t> gcol(NG * W, 0);
-                std::vector<float> gval(NG * W * SCATTER_G, 0.f);
-                gcnt.resize(NG);
-                for (size_t gi = 0; gi < NG; ++gi) {
-                    gcnt[gi] = (int32_t)grows[gi].size();
-                    for (size_t e = 0; e < grows[gi].size(); ++e) {
-                        gcol[gi * W + e] = grows[gi][e].first;
-                        for (int m = 0; m < SCATTER_G; ++m) gval[(gi * W + e) * SCATTER_G + m] = grows[gi][e].second[m];
-                    }
-                }
-                DevEll &d = c.adjT;
-                if (dev_upload(&d.g_cnt, gcnt) || dev_upload(&d.g_col, gcol) || dev_upload(&d.g_val, gval) || dev_upload(&d.g_dst, gdst) ||
-                    dev_upload(&d.g_rmw, grmw))
-                    return bail(1);
-                d.g.NG = (int)NG; d.g.W = W; d.g.cnt = d.g_cnt; d.g.col = d.g_col; d.g.val = d.g_val; d.g.dst = d.g_dst; d.g.rmw = d.g_rmw;
+                if (upload_groups(h, runs, &mask, &c.adjT)) return bail(1);
             }
             c.adjT_host = HostEll();
             if (dev_upload(&c.adjT.rmw, mask)) return bail(1);
