@@ -205,7 +205,12 @@ def main():
             if name.startswith("spmm_"):
                 f16 = os.environ.get("SURFH_WBLUR_F16") != "0" and os.environ.get("SURFH_WBLUR_PC") != "0" and \
                     os.environ.get("SURFH_WBLUR_FP32") != "1" and os.environ.get("SURFH_WBLUR_CC", "2") == "2"
-                return "spmm_rows_f16_kernel" if (f16 and name == "spmm_gather_fwd") else "spmm_rows_kernel"
+                if name == "spmm_gather_fwd" and f16:
+                    return "spmm_group_gather_f16_kernel" if os.environ.get("SURFH_GATHER_GROUPED") != "0" and \
+                        os.environ.get("SURFH_GATHER_SORTED") != "0" else "spmm_rows_f16_kernel"
+                if name == "spmm_scatter_adj" and os.environ.get("SURFH_SCATTER_GROUPED") != "0":
+                    return "spmm_group_scatter_kernel"
+                return "spmm_rows_kernel"
             if name.startswith("gemm_dft_") and name.endswith("_maps"):
                 return "gemm_f32_kernel<64, 64>"
             return name + "_kernel"
