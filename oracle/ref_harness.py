@@ -1,11 +1,13 @@
 """Import the REAL reference hot path from /root/reference  --  TEST INFRASTRUCTURE ONLY.
 
 Works only in the build container (``/root/reference`` does not exist on the GPU
-box).  Used by ``tests/golden/make_golden.py`` to generate golden vectors and by
-``tests/test_oracle_vs_reference.py`` to validate ``oracle/surfh_oracle.py``
-stage by stage.  Nothing is copied: the reference's modules are imported from
-where they lie, and its one native file (``surfh/ToolsDir/cythons_files.pyx``)
-is cythonized + compiled from that path with outputs only under ``oracle/_ref/``.
+box).  Used by ``tests/golden/make_golden.py`` to generate the golden vectors that
+``tests/test_oracle_golden.py`` holds ``oracle/surfh_oracle.py`` to, stage by stage.
+Nothing is copied: the reference's modules are imported from where they lie, and its
+one native file (``surfh/ToolsDir/cythons_files.pyx``) is cythonized + compiled from
+that path with outputs only under a scratch directory OUTSIDE the repository
+(``$SURFH_REF_BUILD`` or ``<tmp>/surfh_ref_build``): nothing compiled from the reference
+is committed or travels to the GPU box.
 
 The snapshot is mid-refactor and depends on packages that are not installed
 (SURVEY.md 8c).  What this harness supplies so that the surviving modules import:
@@ -36,7 +38,9 @@ import numpy as np
 
 REF = "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
-OUT = os.path.join(HERE, "_ref")
+import tempfile  # noqa: E402
+
+OUT = os.environ.get("SURFH_REF_BUILD") or os.path.join(tempfile.gettempdir(), "surfh_ref_build")
 
 
 def available() -> bool:
@@ -44,7 +48,7 @@ def available() -> bool:
 
 
 def build_cython(force=False) -> str:
-    """cythonize + gcc the reference's cythons_files.pyx into oracle/_ref/ (build.py:12-13 flags)."""
+    """cythonize + gcc the reference's cythons_files.pyx into the scratch directory OUT (build.py:12-13 flags)."""
     os.makedirs(OUT, exist_ok=True)
     import sysconfig
     so = os.path.join(OUT, "cythons_files" + sysconfig.get_config_var("EXT_SUFFIX"))
@@ -160,7 +164,7 @@ def load():
     aljabr_linop.Shape = tuple
     sys.modules["aljabr.linop"] = aljabr_linop
 
-    # the reference's compiled native module, loaded from oracle/_ref
+    # the reference's compiled native module, loaded from the scratch build directory
     import importlib.util
     spec = importlib.util.spec_from_file_location("surfh.ToolsDir.cythons_files", so)
     cyf = importlib.util.module_from_spec(spec)

@@ -414,6 +414,13 @@ def gridding_T(tab: ChannelTables, local_cube, p, n_alpha, n_beta):
             out[l] = np.bincount(tab.nn_idx[p], weights=v[l], minlength=n_alpha * n_beta)
         return out.reshape(L, n_alpha, n_beta)
     (i0, i1), (y0, y1) = tab.grid_idx[p], tab.grid_frac[p]
+    if L > 64:      # many planes: the same scatter-add as one sparse product (identical sums up to float64 rounding order)
+        import scipy.sparse as sp
+        nloc = v.shape[1]
+        rows = np.concatenate([(i0 + di) * n_beta + (i1 + dj) for di, dj in ((0, 0), (0, 1), (1, 0), (1, 1))])
+        vals = np.concatenate([(1 - y0) * (1 - y1), (1 - y0) * y1, y0 * (1 - y1), y0 * y1])
+        mat = sp.csr_matrix((vals, (rows, np.tile(np.arange(nloc), 4))), shape=(n_alpha * n_beta, nloc))
+        return np.ascontiguousarray((mat @ v.T).T).reshape(L, n_alpha, n_beta)
     for di, dj, w in ((0, 0, (1 - y0) * (1 - y1)), (0, 1, (1 - y0) * y1),
                       (1, 0, y0 * (1 - y1)), (1, 1, y0 * y1)):
         flat = (i0 + di) * n_beta + (i1 + dj)
@@ -474,12 +481,20 @@ def wblur_subsampling(sliced, wpsf):
     return np.einsum("klb,lab->ka", wpsf, sliced, optimize=True)
 
 
+_WT_CACHE = {}
+
+
 def wblur_t(arr, wpsf):
     """jax_utils.wblur_t (:83-91): x[l,a,b] = sum_l' y[l',a,b] W[l',l,b]."""
-    out = np.empty((wpsf.shape[1], arr.shape[1], arr.shape[2]), dtype=np.result_type(arr, wpsf))
-    for b in range(arr.shape[2]):                      # one BLAS product per beta column
-        out[:, :, b] = wpsf[:, :, b].T @ arr[:, :, b]
-    return out
+    key = (id(wpsf), wpsf.shape)
+    wT = _WT_CACHE.get(key)
+    if wT is None or wT[0] is not wpsf:                # [b][l][l'] contiguous, built once per spectral PSF
+        if len(_WT_CACHE) > 32:
+            _WT_CACHE.clear()
+        wT = (wpsf, np.ascontiguousarray(wpsf.transpose(2, 1, 0)))
+        _WT_CACHE[key] = wT
+    # one batched BLAS product over the beta columns: out[b][l][a] = sum_l' W[l'][l][b] y[l'][a][b]
+    return np.ascontiguousarray(np.matmul(wT[1], np.ascontiguousarray(arr.transpose(2, 0, 1))).transpose(1, 2, 0))
 
 
 def channel_forward(tab: ChannelTables, blurred_cube, box="fft", stages=None):
@@ -512,13 +527,15 @@ def channel_adjoint(tab: ChannelTables, y, alpha_axis, beta_axis, mode="exact", 
     y = y.reshape(tab.oshape)
     inter = np.zeros((Lin, len(alpha_axis), len(beta_axis)))
     bst = box_sum_fft_t if box == "fft" else box_sum_direct_t
+    wconj = tab.wpsf if not np.iscomplexobj(tab.wpsf) else tab.wpsf.conj()      # :251 wpsf.conj(); real in practice
     for p in range(len(tab.pointings)):
         local = np.zeros((Lin, na, nb))
         for s in range(tab.spec.n_slit):
             over = np.repeat(y[p, s][:, :, None], tab.npix_slit_beta_width, axis=2)
             bts = np.zeros(slit_shape)
-            bts[:, : tab.oshape[3] * tab.srf: tab.srf, :] = wblur_t(over, tab.wpsf.conj())
-            local += slicing_t(tab, bts, s, (Lin, na, nb))
+            bts[:, : tab.oshape[3] * tab.srf: tab.srf, :] = wblur_t(over, wconj)
+            sa0, sa1, sb0, sb1 = tab.slit_slices[s]            # local += slicing_t(...) without the full-size temporary
+            local[:, sa0:sa1, sb0:sb1] += bts * tab.slit_weights[s][np.newaxis]
         st = bst(tab, local)
         if stages is not None:
             stages.setdefault("local_cube", []).append(local)

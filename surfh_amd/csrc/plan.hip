@@ -1029,6 +1029,27 @@ int normal_dev(surfh_plan *p, const float *d, float *q, double mu) {
     return 0;
 }
 
+// explicit per-frequency Hessian of Model_WCT and its work buffer: published only once both allocations and the launch
+// that fills `hth` have succeeded (a half-built pair would make the next call skip the launch)
+int ensure_hessian(surfh_plan *p) {
+    if (p->hth && p->mhat2) return 0;
+    float *h = nullptr, *m2 = nullptr;
+    if (dev_alloc(&h, (size_t)p->T * p->T * p->PL) || dev_alloc(&m2, (size_t)p->T * 2 * p->PL)) {
+        hipFree(h);
+        hipFree(m2);
+        return 1;
+    }
+    const int rc = launch_wct_hessian(p->stream, p->sotf, p->tpl, h, p->T, p->PL, p->LP);
+    if (rc != 0) {
+        hipFree(h);
+        hipFree(m2);
+        return fail("launch_wct_hessian failed: %s", hipGetErrorString((hipError_t)rc));
+    }
+    p->hth = h;
+    p->mhat2 = m2;
+    return 0;
+}
+
 int ensure_cg(surfh_plan *p) {
     if (p->cg_x) return 0;
     for (float **v : {&p->cg_x, &p->cg_r, &p->cg_d, &p->cg_q, &p->cg_b})
@@ -1509,10 +1530,7 @@ int surfh_wct_fwadj(surfh_plan *p, const float *x, float *out) {
     if (wct_check(p)) return 1;
     if (!x || !out) return fail("null argument");
     hipStream_t s = p->stream;
-    if (!p->hth) {
-        if (dev_alloc(&p->hth, (size_t)p->T * p->T * p->PL) || dev_alloc(&p->mhat2, (size_t)p->T * 2 * p->PL)) return 1;
-        LAUNCH_OK(launch_wct_hessian(s, p->sotf, p->tpl, p->hth, p->T, p->PL, p->LP));
-    }
+    if (ensure_hessian(p)) return 1;
     HIP_OK(hipMemcpyAsync(p->io_x, x, p->isize * sizeof(float), hipMemcpyHostToDevice, s));
     LAUNCH_OK(launch_pad_planes(s, p->io_x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
@@ -1531,10 +1549,7 @@ int surfh_wct_expsol(surfh_plan *p, const float *cube, const double *mu_reg, con
     for (int t = 0; t < p->T; ++t)
         if (!(mu_reg[t] >= 0.0)) return fail("mu_reg[%d] must be >= 0", t);
     hipStream_t s = p->stream;
-    if (!p->hth) {
-        if (dev_alloc(&p->hth, (size_t)p->T * p->T * p->PL) || dev_alloc(&p->mhat2, (size_t)p->T * 2 * p->PL)) return 1;
-        LAUNCH_OK(launch_wct_hessian(s, p->sotf, p->tpl, p->hth, p->T, p->PL, p->LP));
-    }
+    if (ensure_hessian(p)) return 1;
     // |D(f)|^2 into the padded spectral layout [KAP][KBP]; -1 marks the padding bins
     const int hb = p->Nb / 2 + 1;
     std::vector<float> reg((size_t)p->PL, -1.f);

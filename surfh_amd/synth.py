@@ -30,10 +30,24 @@ BANDS: Dict[str, tuple] = {
 }
 
 
+_WAVEL_TABLE = None
+
+
 def band_wavelengths(name: str) -> np.ndarray:
-    """Detector wavelength axis, CRVAL + CDELT * arange(NAXIS) (wavelength_mrs.py:14-18 form)."""
-    l0, dl, n = BANDS[name][6]
-    return l0 + dl * np.arange(n)
+    """Detector wavelength axis of a sub-band: the reference's table ``global_variables.wavelength_<band>``
+    (surfh/Others/global_variables.py, read by wavelength_mrs.py:22-46), shipped as data in
+    ``surfh_amd/data/mrs_wavelengths.npz`` (written by tests/golden/make_golden.py from the reference; bit-equal,
+    tests/test_host_geometry.py).  The tables are CRVAL + CDELT * arange(NAXIS) evaluated in float32 steps, which a
+    float64 re-evaluation of that formula reproduces only to 3e-8 um (and band 3B's second sample is off the grid by
+    2.5e-4 um in the reference), so the table itself is the single source."""
+    global _WAVEL_TABLE
+    if _WAVEL_TABLE is None:
+        import os
+        with np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "mrs_wavelengths.npz")) as z:
+            _WAVEL_TABLE = {k: np.array(z[k], dtype=np.float64) for k in z.files}
+    wa = _WAVEL_TABLE[name]
+    assert len(wa) == BANDS[name][6][2]
+    return wa.copy()
 
 
 def band_ifu(name: str, angle: float = 8.2, wavel_axis=None) -> instru.IFU:

@@ -183,6 +183,10 @@ def main():
         print(name, "srf", c.srf, "local", c.local_im_shape, "oshape", c.oshape, "wslice", c.wslice)
     g["meta"] = np.array(json.dumps(META))
     np.savez_compressed(os.path.join(HERE, "bands_geometry.npz"), **g)
+    # the 12 detector wavelength axes (surfh/Others/global_variables.py, pure data) as the table the product's driver
+    # and synthetic problems use (surfh_amd/synth.py:band_wavelengths)
+    np.savez_compressed(os.path.join(HERE, "..", "..", "surfh_amd", "data", "mrs_wavelengths.npz"),
+                        **{name: g[f"{name}_wavel"] for name in problems.BANDS})
 
 
 def blurred():

@@ -32,3 +32,15 @@ def test_config_shapes():
     assert p["wavel"].shape == (16,) and p["sotf"].shape == (16, 251, 126) and p["templates"].shape == (4, 16)
     assert [i.name for i in synth.config3(lam_stride=500)["ifus"]] == ["1C", "2A", "2B", "2C"]
     assert len(synth.BANDS) == 12 and synth.band_wavelengths("2a").shape == (970,)
+
+
+def test_band_wavelength_tables_are_the_reference_tables():
+    """synth.band_wavelengths (what scripts/main_fusion.py and the benchmark problems use) == the reference's
+    global_variables.wavelength_<band>, bit for bit (golden file written from the imported reference)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "bands_geometry.npz"))
+    for b in synth.BANDS:
+        assert np.array_equal(synth.band_wavelengths(b), g[b + "_wavel"]), b
+    p3 = synth.config3(lam_stride=500)
+    lo, hi, n = g["axis_cfg3"]
+    assert np.array_equal(np.linspace(lo, hi, int(n))[::500], p3["wavel"])
