@@ -48,4 +48,8 @@ struct DftRx3Args {
     long PL = 0, KBP = 0;
 };
 int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g);
+// the same pass on the wave-specialised kernel (dft_ws.hip): producer waves load / fold / split, consumer waves only feed the
+// matrix cores.  dft_ws_can() says whether it covers the arguments (otherwise use launch_dft_rx3).
+bool dft_ws_can(const DftRx3Args &g);
+int launch_dft_ws(hipStream_t stream, const DftRx3Args &g);
 bool dft_rx3_supported(int Na, int Nb, long NAP, long KBP, long LP);

@@ -147,6 +147,7 @@ struct surfh_plan {
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
     int n_cu = 256;
     int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
+    bool dft_ws = true;                          // DFT passes on the wave-specialised kernel (dft_ws.hip); SURFH_DFT_WS=0: dft_rx3.hip
     bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
     bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
     bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
@@ -714,6 +715,12 @@ int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
 
 // ---- the same two transforms with the symmetry-folded kernel (dft_fold.h): 3x fewer flops --------
 // ---- split-bf16, register-direct variant of the folded passes (dft_rx3.h) ------------------------
+// one pass on the wave-specialised kernel where it covers the shape (default), else on the one-role kernel
+int launch_dft_pass(surfh_plan *p, const DftRx3Args &g) {
+    if (p->dft_ws && dft_ws_can(g)) return launch_dft_ws(p->stream, g);
+    return launch_dft_rx3(p->stream, g);
+}
+
 int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -725,7 +732,7 @@ int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
     g.MP = p->MPb; g.KP = p->KPb; g.N = (int)(p->Na * LP);
     {
         Prof pr(p, "dft_rx3_rows_fwd");
-        LAUNCH_OK(launch_dft_rx3(p->stream, g));
+        LAUNCH_OK(launch_dft_pass(p, g));
     }
     {   // c2c along alpha, batched over k_beta; both output components of a tile back to back (second read from cache)
         DftRx3Args h;
@@ -739,7 +746,7 @@ int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
         h.A_alt[0] = p->Sma3; h.A_alt[1] = p->Cma3; h.fold_alt[0] = -1.f; h.fold_alt[1] = 1.f; h.dst_alt = dst + p->PL * LP;
         h.e_alt[0] = -1.f; h.e_alt[1] = 1.f; h.e_alt[2] = 1.f; h.e_alt[3] = 1.f;
         Prof pr(p, "dft_rx3_cols_fwd");
-        LAUNCH_OK(launch_dft_rx3(p->stream, h));
+        LAUNCH_OK(launch_dft_pass(p, h));
     }
     return 0;
 }
@@ -761,7 +768,7 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
         g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = -1.f; g.e_alt[3] = 1.f;
         if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
         Prof pr(p, mix ? "dft_rx3_cols_inv_mix" : "dft_rx3_cols_inv");
-        LAUNCH_OK(launch_dft_rx3(p->stream, g));
+        LAUNCH_OK(launch_dft_pass(p, g));
     }
     DftRx3Args h;   // c2r along beta, batched over alpha
     h.A[0] = p->Gc3; h.A[1] = p->Gs3; h.planeA = (long)p->MPb * p->KPb; h.lda = p->KPb;
@@ -771,7 +778,7 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
     h.MP = p->MPb; h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
     {
         Prof pr(p, "dft_rx3_rows_inv");
-        LAUNCH_OK(launch_dft_rx3(p->stream, h));
+        LAUNCH_OK(launch_dft_pass(p, h));
     }
     return 0;
 }
@@ -1232,6 +1239,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         const char *e7 = getenv("SURFH_OVERLAP");
         p->overlap = e7 && e7[0] == '1';
         if (p->overlap && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+        const char *e16 = getenv("SURFH_DFT_WS");
+        p->dft_ws = !(e16 && e16[0] == '0');
         const char *e8 = getenv("SURFH_DFT_PACKED");
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");

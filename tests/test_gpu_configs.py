@@ -67,7 +67,7 @@ def test_config3_full_size():
             ws.append((ch.wslice.start, ch.wslice.stop))
             assert ws[-1] == tuple(int(v) for v in g[b + "_wslice_cfg3"]), b         # IFU.wslice of the imported reference
             assert tuple(ch.oshape) == tuple(int(v) for v in g[b + "_oshape"]), b
-            assert tuple(ch.local_im_shape) == tuple(int(v) for v in g[b + "_npix_ab"]), b
+            assert tuple(ch.local_im_shape) == (len(g[b + "_local_alpha_axis"]), len(g[b + "_local_beta_axis"])), b
         assert m.instrs_oshape == [(4, 21, 1400, 19), (4, 17, 970, 24), (4, 17, 1124, 24), (4, 17, 1300, 24)]
         assert list(m._idx) == list(np.cumsum([0] + [int(np.prod(s)) for s in m.instrs_oshape])) and m.ishape == (4, 251, 251)
         assert ws[0][1] > ws[1][0] and ws[1][1] > ws[2][0] and ws[2][1] > ws[3][0]          # neighbouring windows overlap
@@ -124,7 +124,7 @@ def test_config4_all_bands_501():
             ws.append((ch.wslice.start, ch.wslice.stop))
             assert ws[-1] == tuple(int(v) for v in g[b + "_wslice"]), b
             assert tuple(ch.oshape) == tuple(int(v) for v in g[b + "_oshape"]) and ch.srf == int(g[b + "_srf"]), b
-            assert tuple(ch.local_im_shape) == tuple(int(v) for v in g[b + "_npix_ab"]), b
+            assert tuple(ch.local_im_shape) == (len(g[b + "_local_alpha_axis"]), len(g[b + "_local_beta_axis"])), b
         assert [c.srf for c in m.channels] == [7] * 6 + [9] * 3 + [10] * 3
         rng = np.random.default_rng(44)
         y = m.forward(prob["maps"])
