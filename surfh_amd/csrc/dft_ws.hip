@@ -28,8 +28,14 @@ constexpr int BFRAG = 64 * 8;                 // one B fragment of one wave: 64 
 constexpr int BWAVE = 6 * BFRAG;              // (stream 0: h, m, l; stream 1: h, m, l)
 constexpr int BBUF = 4 * BWAVE;               // 24 KB
 constexpr int NB = 2;
-constexpr int RING = 3;                       // k-steps of raw loads a producer holds (RING - 1 in flight behind the one in use)
-constexpr int MIXE = 4;                       // mix-table entries a producer thread stages per tile (256 threads): Kn <= 512
+#ifndef WS_RING
+#define WS_RING 3
+#endif
+#ifndef WS_EXP                                // tools/exp only, bit mask: 1 no data loads, 2 no MFMAs, 4 no stores, 8 no fold / split arithmetic, 16 half the MFMAs
+#define WS_EXP 0
+#endif
+constexpr int RING = WS_RING;                 // k-steps of raw loads a producer holds (RING - 1 in flight behind the one in use)
+constexpr int MIX_ROWS_MAX = 896;             // rows (k) of a tile's spectral-mix table: 2 buffers x (2 x 896 + 128) x 16 B = 60 KB of LDS at most
 constexpr size_t LDS_MAIN = (size_t)(NA * ABUF + NB * BBUF) * sizeof(unsigned short);
 
 __device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
@@ -59,6 +65,21 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4 &fh, uint4 &fm
         asm volatile("" ::: "memory");                  \
     }
 
+#if WS_EXP & 2
+#define MFMA6(acc_, ah_, am_, al_, bh_, bm_, bl_)                                   \
+    {                                                                               \
+        asm volatile("" ::"v"(ah_), "v"(am_), "v"(al_), "v"(bh_), "v"(bm_), "v"(bl_)); \
+    }
+#elif WS_EXP & 16
+#define MFMA6(acc_, ah_, am_, al_, bh_, bm_, bl_)                                   \
+    {                                                                               \
+        f32x16 c_ = acc_;                                                           \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al_, bl_, c_, 0, 0, 0);        \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am_, bm_, c_, 0, 0, 0);        \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, c_, 0, 0, 0);        \
+        acc_ = c_;                                                                  \
+    }
+#else
 #define MFMA6(acc_, ah_, am_, al_, bh_, bm_, bl_)                                   \
     {                                                                               \
         f32x16 c_ = acc_;                                                           \
@@ -70,6 +91,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4 &fh, uint4 &fm
         c_ = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah_, bh_, c_, 0, 0, 0);        \
         acc_ = c_;                                                                  \
     }
+#endif
 
 // KIND 0: two source streams, folded (complex pass); 1: one real source feeding both streams (r2c);
 //      2: two streams, no fold (c2r).  Units are tiles: nvar == 1, or nvar == 2 packed (see dft_rx3.h).
@@ -93,8 +115,8 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
     const unsigned ldb4 = (unsigned)ldbB, ldc4 = (unsigned)ldcB, c4 = (unsigned)lcol * 4u;
     if (S == 0) return;                                        // (the launcher never starts more workgroups than tiles)
     unsigned short *ldsA = lds, *ldsB = lds + NA * ABUF;
-    float4 *mtab = reinterpret_cast<float4 *>(lds + NA * ABUF + NB * BBUF);   // [2][mixn]: mhat column of a tile, [k][re/im] x 4 templates
-    const int mixn = (g.Kn > g.KP ? g.Kn : g.KP) * 2;
+    float4 *mtab = reinterpret_cast<float4 *>(lds + NA * ABUF + NB * BBUF);   // [2][mixs]: mhat column of a tile ([k][re/im] x 4 templates) + template weights of its columns
+    const int mixn = g.mix_rows * 2, mixs = mixn + 128;
 
     if (wave < 4) {
         // ============================================================== consumers
@@ -117,7 +139,30 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
                                              (__attribute__((address_space(3))) void *)(lb + IMG + q * PIECE), 16, 0, 0); \
         }                                                                                                          \
     }
+        // fused spectral mix: the tile's column of mhat ([k][re/im] x 4 templates, laid out by mix_table_kernel) and the template
+        // weights of its columns, global -> LDS buffer i_ & 1 by DMA (no registers): mixn + TN float4
+#define WS_MIXDMA(i_)                                                                                              \
+    {                                                                                                              \
+        const int t_ = (int)blockIdx.x + (i_) * (int)gridDim.x;                                                    \
+        const int n0_ = (t_ % tilesX) * TN;                                                                        \
+        const float4 *src = g.mixtab + (long)(n0_ / g.LP) * mixn;                                                  \
+        float4 *dstb = mtab + ((i_) & 1) * mixs;                                                                   \
+        for (int e = wave * 64; e < mixn; e += 256)        /* mixn is a multiple of 64: whole wave instructions */ \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + e + lane),     \
+                                             (__attribute__((address_space(3))) void *)(dstb + e), 16, 0, 0);      \
+        if (wave * 64 < TN)                                                                                        \
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g.tplT + (n0_ % g.LP) + wave * 64 + lane), \
+                                             (__attribute__((address_space(3))) void *)(dstb + mixn + wave * 64), 16, 0, 0); \
+    }
+        // The data is the A operand and the matrix the B operand of every MFMA (the same register fragments as the other way
+        // round): the accumulators then hold the TRANSPOSED output tile -- lane = output row (within its 32-row block mt),
+        // registers = 32 wavelengths, four consecutive ones per register quad -- so the epilogue is 32 float4 stores per lane
+        // with no transposition.  (With lane = wavelength it was 128 one-dword stores: the wave sat on its full vmcnt queue.)
         f32x16 acc1[4], acc2[4];
+        if (MIX) {
+            WS_MIXDMA(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         WS_BARRIER();                                              // slot -2 (the producers' prologue)
         WS_DMA(0, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -133,6 +178,9 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
             int nkt = kt + 1, nti = ti;
             if (nkt == nk) { nkt = 0; ++nti; }
             if (s + 1 < S) WS_DMA(nti, nkt, (s + 1) & 1);          // that stage was last read before the previous barrier
+            // table of the tile whose first step is s + 3: its buffer was last read two tiles ago; it lands with this slot's wait
+            // and is read from slot s + 2 on
+            if (MIX && kt == nk - 3 && ti + 1 < ntl) WS_MIXDMA(ti + 1);
             {
                 const unsigned short *ra = ldsA + (s & 1) * ABUF + l31 * RS + 8 * (h ^ ((l31 >> 3) & 1));
                 const unsigned short *rb = ldsB + (s & 1) * BBUF + cw * BWAVE + lane * 8;
@@ -145,83 +193,80 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
                     const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(p);
                     const bf16x8 a0m = *reinterpret_cast<const bf16x8 *>(p + PIECE);
                     const bf16x8 a0l = *reinterpret_cast<const bf16x8 *>(p + 2 * PIECE);
-                    MFMA6(acc1[mt], a0h, a0m, a0l, b0h, b0m, b0l)
+                    MFMA6(acc1[mt], b0h, b0m, b0l, a0h, a0m, a0l)       // data x matrix
                     const bf16x8 a1h = *reinterpret_cast<const bf16x8 *>(p + IMG);
                     const bf16x8 a1m = *reinterpret_cast<const bf16x8 *>(p + IMG + PIECE);
                     const bf16x8 a1l = *reinterpret_cast<const bf16x8 *>(p + IMG + 2 * PIECE);
-                    MFMA6(acc2[mt], a1h, a1m, a1l, b1h, b1m, b1l)
+                    MFMA6(acc2[mt], b1h, b1m, b1l, a1h, a1m, a1l)
                 }
             }
-            bool many_stores = false;
+            // the DMA of the next stage has landed (and the previous tile's stores have drained) before this tile's stores are
+            // queued behind it: nothing this wave waits for is ever younger than a store
+            if (s + 1 < S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (kt == nk - 1) {
-                // epilogue of tile ti: uniform base + 32-bit lane offset (the launcher checks the pitches)
+                // epilogue of tile ti.  Register quad q of an accumulator = wavelengths 8 q + 4 h + (0..3) of the wave's 32
+                // (packed: quads 0, 1 = the 16 wavelengths under the first variant's fold, quads 2, 3 = under the second's)
                 const int t = (int)blockIdx.x + ti * (int)gridDim.x;
                 const int tx = t % tilesX, ty = (t / tilesX) % tilesY;
                 const long bz = t / (tilesX * tilesY);
                 const int n0 = tx * TN, em0 = ty * 128;
-                // packed: a second-variant lane holds (acc1, acc2) = (A[0] X_second, A[1] X_first), i.e. that variant's products swapped
-                const float e00 = var ? g.e_alt[1] : g.e00, e01 = var ? g.e_alt[0] : g.e01;
-                const float e10 = var ? g.e_alt[3] : g.e10, e11 = var ? g.e_alt[2] : g.e11;
-                char *D0 = reinterpret_cast<char *>(g.dst[0] + bz * g.sC + n0);
-                const unsigned dvar = var ? (unsigned)((g.dst_alt - g.dst[0]) * 4) : 0u;      // second variant's array, as a lane offset
-                char *D1 = reinterpret_cast<char *>((g.dst[1] ? g.dst[1] : g.dst[0]) + bz * g.sC + n0);
-                char *Dk0 = D0 + (long)em0 * ldcB, *Dk1 = D1 + (long)em0 * ldcB, *Dm0 = D0 + (long)(g.Rn - em0 - 4) * ldcB;
-                const unsigned lo = (unsigned)(4 * h) * ldc4 + c4 + dvar, lm = (unsigned)(4 * (1 - h)) * ldc4 + c4 + dvar;
-                const long s1 = ldcB, s5 = 5 * ldcB;
-                many_stores = g.rvalid - em0 >= 126;               // then at least 63 store instructions follow the DMA above
+                float *D0 = g.dst[0] + bz * g.sC + n0;
+                float *D1 = (g.dst[1] ? g.dst[1] : g.dst[0]) + bz * g.sC + n0;
+                float *DA = packed ? g.dst_alt + bz * g.sC + n0 : D0;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < 4; ++mt) {
+                    const int row = em0 + mt * 32 + l31;
+                    const bool ok = row < g.rvalid, okm = ok && row >= 1 && 2 * row != g.Rn;
+                    const long ro = (long)row * g.ldc, rm = (long)(g.Rn - row) * g.ldc;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = em0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        const float a1 = acc1[mt][r], a2 = acc2[mt][r];
-                        if (row < g.rvalid) {
-                            if (g.mode == 0) {
-                                *reinterpret_cast<float *>(Dk0 + lo) = e00 * a1 + e01 * a2;
-                                if (row >= 1 && 2 * row != g.Rn) *reinterpret_cast<float *>(Dm0 + lm) = e10 * a1 + e11 * a2;
-                            } else {
-                                *reinterpret_cast<float *>(Dk0 + lo) = e00 * a1;
-                                *reinterpret_cast<float *>(Dk1 + lo) = e11 * a2;
+                    for (int q = 0; q < 4; ++q) {
+                        const bool v2 = packed && q >= 2;                       // second variant: products swapped (see dft_rx3.hip)
+                        const float e00 = v2 ? g.e_alt[1] : g.e00, e01 = v2 ? g.e_alt[0] : g.e01;
+                        const float e10 = v2 ? g.e_alt[3] : g.e10, e11 = v2 ? g.e_alt[2] : g.e11;
+                        const int col = packed ? cw * 16 + 8 * (q & 1) + 4 * h : cw * 32 + 8 * q + 4 * h;
+                        float *d0 = (v2 ? DA : D0) + col;
+                        const float a0 = acc1[mt][4 * q], a1 = acc1[mt][4 * q + 1], a2 = acc1[mt][4 * q + 2], a3 = acc1[mt][4 * q + 3];
+                        const float b0 = acc2[mt][4 * q], b1 = acc2[mt][4 * q + 1], b2 = acc2[mt][4 * q + 2], b3 = acc2[mt][4 * q + 3];
+                        if (WS_EXP & 4) {
+                            asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
+                        } else if (g.mode == 0) {
+                            if (ok) *reinterpret_cast<float4 *>(d0 + ro) = make_float4(e00 * a0 + e01 * b0, e00 * a1 + e01 * b1, e00 * a2 + e01 * b2, e00 * a3 + e01 * b3);
+                            if (okm) *reinterpret_cast<float4 *>(d0 + rm) = make_float4(e10 * a0 + e11 * b0, e10 * a1 + e11 * b1, e10 * a2 + e11 * b2, e10 * a3 + e11 * b3);
+                        } else {
+                            if (ok) {
+                                *reinterpret_cast<float4 *>(D0 + col + ro) = make_float4(e00 * a0, e00 * a1, e00 * a2, e00 * a3);
+                                *reinterpret_cast<float4 *>(D1 + col + ro) = make_float4(e11 * b0, e11 * b1, e11 * b2, e11 * b3);
                             }
                         }
-                        const long st = ((r & 3) == 3) ? s5 : s1;
-                        Dk0 += st; Dk1 += st; Dm0 -= st;
                     }
+                }
             }
-            if (s + 1 < S) {
-                // the DMA of the next stage must have landed; the stores behind it may keep draining
-                if (many_stores) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                WS_BARRIER();
-            }
+            if (s + 1 < S) WS_BARRIER();
             kt = nkt;
             ti = nti;
         }
 #undef WS_DMA
+#undef WS_MIXDMA
         return;
     }
 
     // ================================================================== producers
-    const int ptid = tid - 256;
     const int kin = g.Kn / 2 + 1;
     float rx[RING][8], ri[RING][8], rq[RING][8], rp[RING][8];     // raw rows (stream 0 / 1) and their mirror rows, per ring slot
-    float4 twr[RING];                                              // template weights of the lane's column, loaded with a tile's first k-step
-    float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
-    float mt4[MIXE][4];                                            // staged mix-table entries of the next tile
+    float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);                   // template weights of the lane's column (MIX)
     int hv = h;
 
-    // load cursor (step lf): tile li, k-step lkt, source bases of that tile
-    int li = 0, lkt = 0;
+    // load cursor: k-step lstep of this workgroup's stream = k-step lkt of local tile li; it stops at the last step (the loads
+    // behind the end of the stream repeat that step: no branch around a vector load, so the compiler keeps counted waits)
+    int li = 0, lkt = 0, lstep = 0;
     const char *LB0 = nullptr, *LB1 = nullptr;
-    int ln0 = 0;
 #define WS_LSETUP()                                                                                                 \
     {                                                                                                               \
         const int t_ = (int)blockIdx.x + li * (int)gridDim.x;                                                       \
-        const int tx_ = t_ % tilesX;                                                                                \
         const long bz_ = t_ / (tilesX * tilesY);                                                                    \
-        ln0 = tx_ * TN;                                                                                             \
-        LB0 = reinterpret_cast<const char *>(g.src[0] + bz_ * g.sB + ln0);                                          \
-        LB1 = reinterpret_cast<const char *>(g.src[1] + bz_ * g.sB + ln0);                                          \
+        const int n0_ = (t_ % tilesX) * TN;                                                                         \
+        LB0 = reinterpret_cast<const char *>(g.src[0] + bz_ * g.sB + n0_);                                          \
+        LB1 = reinterpret_cast<const char *>(g.src[1] + bz_ * g.sB + n0_);                                          \
     }
     // raw loads of this lane's 8 k of k-step lkt (k = 16 kt + 8 h + j) and of their mirror rows; branch-free so that all of
     // them are in flight together.  Row part of every address in 64-bit scalar pointers, lane part in one small VGPR.
@@ -233,6 +278,7 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
         const char *rp0 = LB0 + (long)(g.Kn - lkt * BK - 8) * ldbB, *rp1 = LB1 + (long)(g.Kn - lkt * BK - 8) * ldbB; \
         const unsigned vk = (unsigned)(8 * hv) * ldb4 + c4, vp = (unsigned)(8 * (1 - hv)) * ldb4 + c4;              \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
+            if (WS_EXP & 1) { rx[r_][j] = ri[r_][j] = rq[r_][j] = rp[r_][j] = (float)(lstep + j); continue; }     \
             rx[r_][j] = *reinterpret_cast<const float *>(rk0 + j * ldbB + vk);                                     \
             if (KIND != 1) ri[r_][j] = *reinterpret_cast<const float *>(rk1 + j * ldbB + vk);                      \
             if (KIND != 2) {                                                                                       \
@@ -241,38 +287,16 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
                 if (KIND != 1) rp[r_][j] = *reinterpret_cast<const float *>(rp1 - j * ldbB + q);                   \
             }                                                                                                      \
         }                                                                                                          \
-        if (MIX && lkt == 0) {                                                                                     \
-            const int l = (ln0 % g.LP) + lcol;                                                                     \
-            float t4[4];                                                                                           \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t) t4[t] = (t < g.T) ? g.tpl[(long)t * g.LP + l] : 0.f;     \
-            twr[r_] = make_float4(t4[0], t4[1], t4[2], t4[3]);                                                     \
-        }                                                                                                          \
-        if (++lkt == nk) { lkt = 0; ++li; if (li < ntl) WS_LSETUP(); }                                             \
-    }
-    // mix table of local tile i_: global loads into registers (issue), registers into LDS buffer i_ & 1 (write)
-#define WS_MIX_ISSUE(i_)                                                                                            \
-    {                                                                                                               \
-        const int t_ = (int)blockIdx.x + (i_) * (int)gridDim.x;                                                     \
-        const int kb = ((t_ % tilesX) * TN) / g.LP;                                                                 \
-        _Pragma("unroll") for (int u = 0; u < MIXE; ++u) {                                                         \
-            const int e = ptid + 256 * u, k = e >> 1, c = e & 1;                                                   \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                          \
-                mt4[u][t] = (e < mixn && t < g.T && k < g.Kn) ? g.mhat[((long)t * 2 + c) * g.PL + (long)k * g.KBP + kb] : 0.f; \
-        }                                                                                                          \
-    }
-#define WS_MIX_WRITE(i_)                                                                                            \
-    {                                                                                                               \
-        float4 *mb = mtab + ((i_) & 1) * mixn;                                                                      \
-        _Pragma("unroll") for (int u = 0; u < MIXE; ++u) {                                                         \
-            const int e = ptid + 256 * u;                                                                          \
-            if (e < mixn) mb[e] = make_float4(mt4[u][0], mt4[u][1], mt4[u][2], mt4[u][3]);                         \
+        if (lstep + 1 < S) {                                                                                       \
+            ++lstep;                                                                                               \
+            if (++lkt == nk) { lkt = 0; ++li; WS_LSETUP(); }                                                       \
         }                                                                                                          \
     }
     // fold (and mix) ring slot r_ = k-step fkt of tile fi into the two data streams, split, store as B fragments of stage st_
 #define WS_FOLD(r_, st_)                                                                                            \
     {                                                                                                               \
-        if (MIX && fkt == 0) tw = twr[r_];                                                                          \
-        const float4 *mb = mtab + (fi & 1) * mixn;                                                                  \
+        const float4 *mb = mtab + (fi & 1) * mixs;                                                                  \
+        if (MIX && fkt == 0) tw = mb[mixn + lcol];                                                                  \
         float x0[8], x1[8];                                                                                         \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
             const int k = fkt * BK + 8 * hv + j;                                                                    \
@@ -309,49 +333,48 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
             }                                                                                                      \
         }                                                                                                          \
         uint4 f0h, f0m, f0l, f1h, f1m, f1l;                                                                        \
+        if (WS_EXP & 8) {                                                                                          \
+            f0h = make_uint4(__float_as_uint(rx[r_][0]), __float_as_uint(rx[r_][1]), __float_as_uint(rx[r_][2]), __float_as_uint(rx[r_][3])); \
+            f0m = make_uint4(__float_as_uint(rx[r_][4]), __float_as_uint(rx[r_][5]), __float_as_uint(rx[r_][6]), __float_as_uint(rx[r_][7])); \
+            f0l = f0h; f1h = f0m; f1m = f0h; f1l = f0m;                                                            \
+            if (KIND != 1) { f1h.x ^= __float_as_uint(ri[r_][0] + ri[r_][1] + ri[r_][2] + ri[r_][3] + ri[r_][4] + ri[r_][5] + ri[r_][6] + ri[r_][7]); } \
+            if (KIND != 2) { f1m.x ^= __float_as_uint(rq[r_][0] + rq[r_][1] + rq[r_][2] + rq[r_][3] + rq[r_][4] + rq[r_][5] + rq[r_][6] + rq[r_][7]); } \
+            if (KIND == 0) { f1l.x ^= __float_as_uint(rp[r_][0] + rp[r_][1] + rp[r_][2] + rp[r_][3] + rp[r_][4] + rp[r_][5] + rp[r_][6] + rp[r_][7]); } \
+        } else {                                                                                                   \
         split8(x0, f0h, f0m, f0l);                                                                                  \
         split8(x1, f1h, f1m, f1l);                                                                                  \
+        }                                                                                                          \
         uint4 *wb = reinterpret_cast<uint4 *>(ldsB + (st_) * BBUF + cw * BWAVE) + lane;                            \
         wb[0] = f0h; wb[64] = f0m; wb[128] = f0l; wb[192] = f1h; wb[256] = f1m; wb[320] = f1l;                     \
         if (++fkt == nk) { fkt = 0; ++fi; }                                                                        \
     }
 
-    // ---- slot -2: first RING k-steps of loads in flight, mix table of tile 0
-    if (ntl > 0) WS_LSETUP();
+    // ---- slot -2: the first RING k-steps of loads in flight
+    WS_LSETUP();
 #pragma unroll
-    for (int r = 0; r < RING; ++r)
-        if (r < S) WS_LOAD(r);
-    if (MIX && ntl > 0) {
-        WS_MIX_ISSUE(0);
-        WS_MIX_WRITE(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    for (int r = 0; r < RING; ++r) WS_LOAD(r);
     WS_BARRIER();
     // ---- slots -1 .. S-2: in slot f - 1 fold k-step f (ring slot f % RING), then refill that ring slot with k-step f + RING
-    int fi = 0, fkt = 0;
-    for (int f0 = 0; f0 < S; f0 += RING) {
+    int fi = 0, fkt = 0, f0 = 0;
+    for (; f0 + RING <= S; f0 += RING) {
         asm volatile("" : "+v"(hv));   // keeps the per-lane fold selectors from being hoisted out of the loop
 #pragma unroll
         for (int r = 0; r < RING; ++r) {
-            const int f = f0 + r;
-            if (f < S) {
-                WS_FOLD(r, f & 1);
-                if (f + RING < S) WS_LOAD(r);
-                if (MIX) {
-                    // tile i's table is read from slot (first step of i) - 1 on: registers filled two slots, LDS one slot earlier
-                    const int a = f + 2, b = f + 1;          // slots f - 1 = s_i0 - 3 and s_i0 - 2  <=>  s_i0 = f + 2 and f + 1
-                    if (a % nk == 0 && a < S) WS_MIX_ISSUE(a / nk);
-                    if (b % nk == 0 && b < S && b > 0) WS_MIX_WRITE(b / nk);
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                WS_BARRIER();
-            }
+            WS_FOLD(r, (f0 + r) & 1);
+            WS_LOAD(r);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WS_BARRIER();
         }
     }
+#pragma unroll
+    for (int r = 0; r < RING - 1; ++r)      // the last S % RING k-steps: nothing left to load
+        if (f0 + r < S) {
+            WS_FOLD(r, (f0 + r) & 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            WS_BARRIER();
+        }
 #undef WS_LSETUP
 #undef WS_LOAD
-#undef WS_MIX_ISSUE
-#undef WS_MIX_WRITE
 #undef WS_FOLD
 }
 
@@ -369,9 +392,10 @@ bool dft_ws_can(const DftRx3Args &g) {
         // the packed form keeps A[0], A[1] for both variants: the second variant's matrices must be the first one's, swapped
         if (g.A_alt[0] != g.A[1] || g.A_alt[1] != g.A[0]) return false;
     } else if (g.N % 128) return false;
-    if (g.mhat) {
-        const int mixn = (g.Kn > g.KP ? g.Kn : g.KP) * 2;
-        if (kind != 0 || g.nvar != 2 || g.LP % 128 || g.T < 1 || g.T > 4 || mixn > 256 * MIXE || g.KP / BK < 3) return false;
+    if (g.mhat) {      // fused spectral mix: needs the table built by launch_dft_ws_mix_table and whole-DMA table sizes
+        if (kind != 0 || g.nvar != 2 || g.LP % 128 || g.T < 1 || g.T > 4 || g.KP / BK < 3 || !g.mixtab || !g.tplT ||
+            g.mix_rows % 32 || g.mix_rows < g.Kn || g.mix_rows < g.KP || g.mix_rows > MIX_ROWS_MAX)
+            return false;
     }
     return true;
 }
@@ -395,11 +419,10 @@ int launch_dft_ws(hipStream_t stream, const DftRx3Args &g) {
     a.strided = 0;
     const long ntile = (long)(g.N / (a.packed ? 64 : 128)) * (g.MP / 128) * g.batch;
     dim3 grid((unsigned)(ntile < cus_of[dev] ? ntile : cus_of[dev]));
-    const int mixn = (g.Kn > g.KP ? g.Kn : g.KP) * 2;
-    const size_t mix_bytes = g.mhat ? (size_t)2 * mixn * sizeof(float4) : 0;
+    const size_t mix_bytes = g.mhat ? (size_t)2 * (2 * g.mix_rows + 128) * sizeof(float4) : 0;
     static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
     if (g.mhat) {
-        if (int e = ensure_dynamic_lds(dft_ws_kernel<0, true>, LDS_MAIN + (size_t)2 * 256 * MIXE * sizeof(float4), d3)) return e;
+        if (int e = ensure_dynamic_lds(dft_ws_kernel<0, true>, LDS_MAIN + (size_t)2 * (2 * MIX_ROWS_MAX + 128) * sizeof(float4), d3)) return e;
         hipLaunchKernelGGL((dft_ws_kernel<0, true>), grid, dim3(512), LDS_MAIN + mix_bytes, stream, a);
     } else if (kind == 0) {
         if (int e = ensure_dynamic_lds(dft_ws_kernel<0, false>, LDS_MAIN, d0)) return e;
@@ -411,5 +434,32 @@ int launch_dft_ws(hipStream_t stream, const DftRx3Args &g) {
         if (int e = ensure_dynamic_lds(dft_ws_kernel<2, false>, LDS_MAIN, d2)) return e;
         hipLaunchKernelGGL((dft_ws_kernel<2, false>), grid, dim3(512), LDS_MAIN, stream, a);
     }
+    return (int)hipGetLastError();
+}
+
+// mixtab[kb][2 k + c] = (mhat[t][c][k][kb], t = 0..3), zero for t >= T and for k >= Kn: the per-tile table of the fused
+// spectral mix in the layout the pass kernel moves to LDS by DMA (one contiguous block of 2 * mix_rows float4 per kb)
+namespace {
+__global__ __launch_bounds__(256) void mix_table_kernel(const float *__restrict__ mhat, float4 *__restrict__ out, int T, int Kn, int nkb,
+                                                        long PL, long KBP, int mix_rows) {
+    const int kb = blockIdx.x * 64 + (threadIdx.x & 63);          // kb fastest: contiguous reads of mhat
+    const int e = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (kb >= nkb || e >= 2 * mix_rows) return;
+    const int k = e >> 1, c = e & 1;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if (k < Kn)
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+            if (t < T) v[t] = mhat[((long)t * 2 + c) * PL + (long)k * KBP + kb];
+    out[(long)kb * 2 * mix_rows + e] = make_float4(v[0], v[1], v[2], v[3]);
+}
+}  // namespace
+
+int dft_ws_mix_rows(int Kn, int KP) { return ((Kn > KP ? Kn : KP) + 31) / 32 * 32; }
+
+int launch_dft_ws_mix_table(hipStream_t stream, const float *mhat, float *mixtab, int T, int Kn, int nkb, long PL, long KBP, int mix_rows) {
+    if (T < 1 || T > 4 || nkb < 1 || mix_rows < Kn || mix_rows % 32) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)((nkb + 63) / 64), (unsigned)((2 * mix_rows + 3) / 4));
+    hipLaunchKernelGGL(mix_table_kernel, grid, dim3(256), 0, stream, mhat, reinterpret_cast<float4 *>(mixtab), T, Kn, nkb, PL, KBP, mix_rows);
     return (int)hipGetLastError();
 }

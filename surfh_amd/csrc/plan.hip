@@ -159,6 +159,8 @@ struct surfh_plan {
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
+    float *mixtab = nullptr, *tplT = nullptr;    // fused spectral mix of the wave-specialised pass: [hb][2 mix_rows] x 4 and [LP] x 4 (dft_rx3.h)
+    int mix_rows = 0;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
     // CG
@@ -766,7 +768,17 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
         g.A_alt[0] = p->Sma3; g.A_alt[1] = p->Cma3; g.fold_alt[0] = -1.f; g.fold_alt[1] = 1.f;
         g.dst_alt = p->ycol + (long)p->NAP * p->KBP * LP;
         g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = -1.f; g.e_alt[3] = 1.f;
-        if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
+        if (mix) {
+            g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP;
+            if (p->dft_ws && p->mixtab) {     // the wave-specialised kernel takes the mix as per-tile tables it moves to LDS by DMA
+                g.mixtab = reinterpret_cast<const float4 *>(p->mixtab); g.tplT = reinterpret_cast<const float4 *>(p->tplT);
+                g.mix_rows = p->mix_rows;
+                if (dft_ws_can(g)) {
+                    Prof pr(p, "mix_table");
+                    LAUNCH_OK(launch_dft_ws_mix_table(p->stream, p->mhat, p->mixtab, p->T, p->Na, hb, p->PL, p->KBP, p->mix_rows));
+                }
+            }
+        }
         Prof pr(p, mix ? "dft_rx3_cols_inv_mix" : "dft_rx3_cols_inv");
         LAUNCH_OK(launch_dft_pass(p, g));
     }
@@ -1079,7 +1091,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipSetDevice(p->dev);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
-                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
+                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->mixtab, p->tplT, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
         hipFree(v);
     hipFree(p->dft3);
     hipFree(p->dscal);
@@ -1312,6 +1324,14 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             p->Cma3 = p->dft3 + off[0]; p->Sma3 = p->dft3 + off[1]; p->Gc3 = p->dft3 + off[2];
             p->Gs3 = p->dft3 + off[3]; p->Cf3 = p->dft3 + off[4]; p->Sf3 = p->dft3 + off[5];
         }
+    }
+    if (p->T > 0 && p->T <= 4 && p->rx3 && p->dft_ws) {   // tables of the fused spectral mix (wave-specialised pass)
+        p->mix_rows = dft_ws_mix_rows(p->Na, p->KPa);
+        std::vector<float> tT((size_t)LP * 4, 0.f);
+        for (int k = 0; k < p->T; ++k)
+            for (int l = 0; l < p->Lown; ++l)
+                if (p->planes[l] >= 0) tT[(size_t)l * 4 + k] = (float)cfg->templates[(size_t)k * p->Lc + p->planes[l]];
+        if (dev_upload(&p->tplT, tT) || dev_alloc(&p->mixtab, (size_t)(p->Nb / 2 + 1) * 2 * p->mix_rows * 4)) return bail(1);
     }
     // ---- work buffers ---------------------------------------------------------------------
     const size_t nspec = (size_t)2 * p->PL * LP, ncube = (size_t)p->NBP * p->NAP * LP;
