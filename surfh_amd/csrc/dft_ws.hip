@@ -1,21 +1,35 @@
 // Wave-specialised form of the split-bf16 folded DFT pass (arithmetic, operand layout and arguments of dft_rx3.h).
 //
-// One persistent workgroup of 8 waves per CU.  Waves 4-7 are PRODUCERS: each owns 32 columns (lambda) of the tile, loads the
-// 8 (+8 mirror) rows of its lane's column of every k-step straight from HBM, three k-steps ahead of their use (a register
-// ring, so that two k-steps of loads per wave are always in flight), folds them, optionally forms the spectral mix, cuts the
-// values into their three bf16 pieces and writes them to LDS ALREADY AS MFMA B FRAGMENTS (lane-linear 16-byte stores: no
-// transposition, no bank conflicts).  Waves 0-3 are CONSUMERS: they move the cos / sin matrix tiles of the next k-step into
-// LDS by LDS-DMA, read A and B fragments and issue the 48 MFMAs of a k-step -- nothing else, until the tile's epilogue
-// stores.  A producer shares its SIMD with the consumer of the same number, so its VALU work issues beside the
-// partner's MFMAs instead of in front of them (in dft_rx3.hip both were one wave's instruction stream: the pass took the
-// SUM of its matrix-core, fold / split and memory times).  One raw s_barrier per k-step hands a stage over; the pipeline runs
-// across tile seams; stores drain in the background (the consumers never wait for them: at a tile's last k-step the
-// LDS-DMA of the next stage is known to have landed once 63 younger stores have been issued, s_waitcnt vmcnt(63)).
+// One persistent workgroup of 8 waves per CU walks a contiguous range of tiles; a tile is 128 output rows x 128 columns
+// (lambda), 64 columns for the packed complex pass.  Waves 4-7 are PRODUCERS, waves 0-3 CONSUMERS; wave w + 4 and wave w share a
+// SIMD, so the producer's vector work issues beside its partner's MFMAs.  One raw s_barrier per k-step hands a stage over.
+//
+// What each wave may wait for decides the structure.  vmcnt is ONE in-order counter per wave: a wave with slow operations in
+// flight (stores draining at the chip's write rate; data loads two k-steps ahead) cannot wait for a younger, short one
+// without waiting for everything in front of it.  And a kernel that contains LDS-DMA (global_load_lds) makes hipcc put
+// s_waitcnt vmcnt(0) in front of EVERY LDS access of every wave (it cannot tell which DMA an access may alias).  Measured
+// dead ends, each correct: consumers that issued the matrix DMA and the stores (every k-step after an epilogue waited for
+// that tile's stores: time = compute + stores + loads); data as the MFMA A operand (row-per-lane float4 stores: 64 scattered
+// 16-byte pieces per instruction, slower than 128 dword stores); producers with LDS-DMA rings (the inserted waits drained them).
+//   * Producers use plain global loads into TWO register sets and write them to LDS two k-steps later (raw fp32 rows of the
+//     fold -- mirror rows included -- as whole 512-byte row pieces, the cos / sin matrix tile, the template weights of the
+//     lane's column): the compiler counts these loads exactly, one set stays in flight while the other is written.  They then
+//     read their lane's rows from LDS, fold, form the spectral mix, split into three bf16 pieces and store them to LDS ALREADY
+//     AS MFMA B FRAGMENTS (lane-linear 16-byte stores).
+//   * Consumers never wait on vmcnt: fragment reads, 48 MFMAs per k-step, and per tile an epilogue that sends the
+//     accumulators through the (just consumed) B-fragment stage of the wave to turn "lane = column" into 16-byte rows:
+//     32 float4 stores per lane and tile (eight 128-byte row segments per instruction) instead of 128 one-dword stores, which
+//     queue (< 63 outstanding) and drain while the next tile is computed.
 #include "dft_rx3.h"
 #include "lds_attr.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));      // (arrays of HIP's float4 / uint4 structs are copied with memcpy and end up in scratch)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// loads through pointers the compiler cannot prove global (selected per thread, carried across the loop) would be flat loads,
+// which also count in lgkmcnt and would be drained by every LDS wait
+#define WS_GLOBAL(T_, p_) (*((const __attribute__((address_space(1))) T_ *)(p_)))
 
 namespace {
 
@@ -28,14 +42,10 @@ constexpr int BFRAG = 64 * 8;                 // one B fragment of one wave: 64 
 constexpr int BWAVE = 6 * BFRAG;              // (stream 0: h, m, l; stream 1: h, m, l)
 constexpr int BBUF = 4 * BWAVE;               // 24 KB
 constexpr int NB = 2;
-#ifndef WS_RING
-#define WS_RING 3
-#endif
-#ifndef WS_EXP                                // tools/exp only, bit mask: 1 no data loads, 2 no MFMAs, 4 no stores, 8 no fold / split arithmetic, 16 half the MFMAs
+#ifndef WS_EXP                                // tools/exp only, bit mask: 1 no raw-data DMA, 2 no MFMAs, 4 no stores, 8 no fold / split arithmetic, 16 half the MFMAs, 32 no matrix loads, 64 no L2 prefetch
 #define WS_EXP 0
 #endif
-constexpr int RING = WS_RING;                 // k-steps of raw loads a producer holds (RING - 1 in flight behind the one in use)
-constexpr int MIX_ROWS_MAX = 896;             // rows (k) of a tile's spectral-mix table: 2 buffers x (2 x 896 + 128) x 16 B = 60 KB of LDS at most
+constexpr int MIX_ROWS_MAX = 1024;            // rows (k) of the spectral-mix table held in LDS: 2 x 1024 x 16 B = 32 KB at most (160 KB in all)
 constexpr size_t LDS_MAIN = (size_t)(NA * ABUF + NB * BBUF) * sizeof(unsigned short);
 
 __device__ __forceinline__ unsigned pack2(unsigned a, unsigned b) { return __builtin_amdgcn_perm(b, a, 0x07060302u); }
@@ -93,80 +103,38 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4 &fh, uint4 &fm
     }
 #endif
 
-// KIND 0: two source streams, folded (complex pass); 1: one real source feeding both streams (r2c);
-//      2: two streams, no fold (c2r).  Units are tiles: nvar == 1, or nvar == 2 packed (see dft_rx3.h).
+// KIND 0: two source streams, folded, PACKED (complex pass, both output components from one read of a 64-column tile);
+//      1: one real source feeding both streams (r2c); 2: two streams, no fold (c2r).
 template <int KIND, bool MIX>
 __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 3;                                   // which 32 columns of the tile
+    const int cw = wave & 3;                                   // which 32 lanes-worth of columns of the tile
     const int l31 = lane & 31, h = lane >> 5;
-    const bool packed = (KIND == 0) && g.packed;
-    const int TN = packed ? 64 : 128;
-    const int var = packed ? (l31 >> 4) : 0;
+    constexpr bool packed = (KIND == 0);
+    constexpr int TN = packed ? 64 : 128;                      // columns of a tile
+    const int var = packed ? (l31 >> 4) : 0;                   // packed: which variant this lane's column copy carries
     const int lcol = packed ? cw * 16 + (l31 & 15) : cw * 32 + l31;
     const int tilesX = g.N / TN, tilesY = g.MP / 128;
-    const int ntile = tilesX * tilesY * g.batch;
+    const long ntile = (long)tilesX * tilesY * g.batch;
     const int nk = g.KP / BK;
-    const int ntl = ((int)blockIdx.x < ntile) ? (ntile - 1 - (int)blockIdx.x) / (int)gridDim.x + 1 : 0;
+    // this workgroup's tiles: the contiguous range [t0, t1) (neighbouring tiles share the spectral-mix table and memory pages)
+    const long t0 = ntile * (long)blockIdx.x / (long)gridDim.x, t1 = ntile * ((long)blockIdx.x + 1) / (long)gridDim.x;
+    const int ntl = (int)(t1 - t0);
     const int S = ntl * nk;                                    // k-steps this workgroup runs, over all its tiles
-    const long ldbB = g.ldb * 4, ldcB = g.ldc * 4;
-    const unsigned ldb4 = (unsigned)ldbB, ldc4 = (unsigned)ldcB, c4 = (unsigned)lcol * 4u;
-    if (S == 0) return;                                        // (the launcher never starts more workgroups than tiles)
+    if (S == 0) return;
     unsigned short *ldsA = lds, *ldsB = lds + NA * ABUF;
-    float4 *mtab = reinterpret_cast<float4 *>(lds + NA * ABUF + NB * BBUF);   // [2][mixs]: mhat column of a tile ([k][re/im] x 4 templates) + template weights of its columns
-    const int mixn = g.mix_rows * 2, mixs = mixn + 128;
+    float4 *mtab = reinterpret_cast<float4 *>(lds + NA * ABUF + NB * BBUF);      // [2 mix_rows] mhat column of the tile's kb (fused spectral mix)
+    const int mixn = g.mix_rows * 2;
+    // k_beta of local tile i (uniform): the spectral-mix table changes where it does
+    auto kb_of = [&](int i) { return (int)((((t0 + i) % tilesX) * TN) / g.LP); };
 
     if (wave < 4) {
         // ============================================================== consumers
-        const int arow = tid >> 1;                                 // = 32 * wave + (lane >> 1): the matrix row this lane moves
-        const unsigned aoff = (unsigned)(arow * g.lda + 8 * ((lane & 1) ^ ((arow >> 3) & 1))) * 2u;
-        // matrix tiles: global -> LDS by DMA, lane-linear; position 2*row + c holds the k-half c ^ ((row >> 3) & 1) of the row,
-        // which makes the fragment reads (ds_read_b128, 16-lane groups) conflict-free.  Wave w fills rows 32w..32w+31.
-#define WS_DMA(i_, kt_, st_)                                                                                       \
-    {                                                                                                              \
-        const int t_ = (int)blockIdx.x + (i_) * (int)gridDim.x;                                                    \
-        const int m0_ = ((t_ / tilesX) % tilesY) * 128;                                                            \
-        const char *A0 = reinterpret_cast<const char *>(g.A[0] + (long)m0_ * g.lda);                               \
-        const char *A1 = reinterpret_cast<const char *>(g.A[1] + (long)m0_ * g.lda);                               \
-        const unsigned ao = aoff + (unsigned)((kt_) * BK) * 2u;                                                    \
-        unsigned short *lb = ldsA + (st_) * ABUF + wave * 512;                                                     \
-        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                            \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A0 + 2 * q * g.planeA + ao), \
-                                             (__attribute__((address_space(3))) void *)(lb + q * PIECE), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(A1 + 2 * q * g.planeA + ao), \
-                                             (__attribute__((address_space(3))) void *)(lb + IMG + q * PIECE), 16, 0, 0); \
-        }                                                                                                          \
-    }
-        // fused spectral mix: the tile's column of mhat ([k][re/im] x 4 templates, laid out by mix_table_kernel) and the template
-        // weights of its columns, global -> LDS buffer i_ & 1 by DMA (no registers): mixn + TN float4
-#define WS_MIXDMA(i_)                                                                                              \
-    {                                                                                                              \
-        const int t_ = (int)blockIdx.x + (i_) * (int)gridDim.x;                                                    \
-        const int n0_ = (t_ % tilesX) * TN;                                                                        \
-        const float4 *src = g.mixtab + (long)(n0_ / g.LP) * mixn;                                                  \
-        float4 *dstb = mtab + ((i_) & 1) * mixs;                                                                   \
-        for (int e = wave * 64; e < mixn; e += 256)        /* mixn is a multiple of 64: whole wave instructions */ \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + e + lane),     \
-                                             (__attribute__((address_space(3))) void *)(dstb + e), 16, 0, 0);      \
-        if (wave * 64 < TN)                                                                                        \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(g.tplT + (n0_ % g.LP) + wave * 64 + lane), \
-                                             (__attribute__((address_space(3))) void *)(dstb + mixn + wave * 64), 16, 0, 0); \
-    }
-        // The data is the A operand and the matrix the B operand of every MFMA (the same register fragments as the other way
-        // round): the accumulators then hold the TRANSPOSED output tile -- lane = output row (within its 32-row block mt),
-        // registers = 32 wavelengths, four consecutive ones per register quad -- so the epilogue is 32 float4 stores per lane
-        // with no transposition.  (With lane = wavelength it was 128 one-dword stores: the wave sat on its full vmcnt queue.)
         f32x16 acc1[4], acc2[4];
-        if (MIX) {
-            WS_MIXDMA(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        WS_BARRIER();                                              // slot -2 (the producers' prologue)
-        WS_DMA(0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        WS_BARRIER();                                              // slot -1: matrix tiles and B fragments of step 0 are in LDS
+        WS_BARRIER();                                              // end of the producers' prologue
+        WS_BARRIER();                                              // end of body 0: matrix tile and B fragments of k-step 0 are in LDS
         int ti = 0, kt = 0;
         for (int s = 0; s < S; ++s) {
             if (kt == 0) {
@@ -175,12 +143,8 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
             }
-            int nkt = kt + 1, nti = ti;
-            if (nkt == nk) { nkt = 0; ++nti; }
-            if (s + 1 < S) WS_DMA(nti, nkt, (s + 1) & 1);          // that stage was last read before the previous barrier
-            // table of the tile whose first step is s + 3: its buffer was last read two tiles ago; it lands with this slot's wait
-            // and is read from slot s + 2 on
-            if (MIX && kt == nk - 3 && ti + 1 < ntl) WS_MIXDMA(ti + 1);
+            // the producers reload the mix table between two barriers when the next tile belongs to another k_beta
+            if (MIX && kt == nk - 1 && ti + 1 < ntl && kb_of(ti + 1) != kb_of(ti)) WS_BARRIER();
             {
                 const unsigned short *ra = ldsA + (s & 1) * ABUF + l31 * RS + 8 * (h ^ ((l31 >> 3) & 1));
                 const unsigned short *rb = ldsB + (s & 1) * BBUF + cw * BWAVE + lane * 8;
@@ -193,131 +157,177 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
                     const bf16x8 a0h = *reinterpret_cast<const bf16x8 *>(p);
                     const bf16x8 a0m = *reinterpret_cast<const bf16x8 *>(p + PIECE);
                     const bf16x8 a0l = *reinterpret_cast<const bf16x8 *>(p + 2 * PIECE);
-                    MFMA6(acc1[mt], b0h, b0m, b0l, a0h, a0m, a0l)       // data x matrix
+                    MFMA6(acc1[mt], a0h, a0m, a0l, b0h, b0m, b0l)
                     const bf16x8 a1h = *reinterpret_cast<const bf16x8 *>(p + IMG);
                     const bf16x8 a1m = *reinterpret_cast<const bf16x8 *>(p + IMG + PIECE);
                     const bf16x8 a1l = *reinterpret_cast<const bf16x8 *>(p + IMG + 2 * PIECE);
-                    MFMA6(acc2[mt], b1h, b1m, b1l, a1h, a1m, a1l)
+                    MFMA6(acc2[mt], a1h, a1m, a1l, b1h, b1m, b1l)
                 }
             }
-            // the DMA of the next stage has landed (and the previous tile's stores have drained) before this tile's stores are
-            // queued behind it: nothing this wave waits for is ever younger than a store
-            if (s + 1 < S) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (kt == nk - 1) {
-                // epilogue of tile ti.  Register quad q of an accumulator = wavelengths 8 q + 4 h + (0..3) of the wave's 32
-                // (packed: quads 0, 1 = the 16 wavelengths under the first variant's fold, quads 2, 3 = under the second's)
-                const int t = (int)blockIdx.x + ti * (int)gridDim.x;
-                const int tx = t % tilesX, ty = (t / tilesX) % tilesY;
-                const long bz = t / (tilesX * tilesY);
+                // Epilogue of tile ti.  An accumulator holds a column (lane) x 16 rows (registers); half a 32-row block at a time
+                // goes through this wave's 6 KB of the B-fragment stage it has just consumed (free until the next barrier) as
+                // [16 rows][32 columns] floats, and comes back as float4 row pieces: lane L = row L >> 3, columns 4 (L & 7)...
+                const long t = t0 + ti;
+                const int tx = (int)(t % tilesX), ty = (int)((t / tilesX) % tilesY);
+                const long bz = t / ((long)tilesX * tilesY);
                 const int n0 = tx * TN, em0 = ty * 128;
-                float *D0 = g.dst[0] + bz * g.sC + n0;
-                float *D1 = (g.dst[1] ? g.dst[1] : g.dst[0]) + bz * g.sC + n0;
-                float *DA = packed ? g.dst_alt + bz * g.sC + n0 : D0;
+                // packed: a second-variant lane holds (acc1, acc2) = (A[0] X_second, A[1] X_first), i.e. that variant's products swapped
+                const float e00 = var ? g.e_alt[1] : g.e00, e01 = var ? g.e_alt[0] : g.e01;
+                const float e10 = var ? g.e_alt[3] : g.e10, e11 = var ? g.e_alt[2] : g.e11;
+                float *stg = reinterpret_cast<float *>(ldsB + (s & 1) * BBUF + cw * BWAVE);       // two buffers of 16 x 32 floats
+                const int rrow = lane >> 3, cg = lane & 7;
+                const int rvar = packed ? (cg >> 2) : 0;
+                float *Dv = (rvar ? g.dst_alt : g.dst[0]) + bz * g.sC + n0 + (packed ? cw * 16 + 4 * (cg & 3) : cw * 32 + 4 * cg);
+                float *D1 = (g.dst[1] ? g.dst[1] : g.dst[0]) + bz * g.sC + n0 + cw * 32 + 4 * cg;   // SPLIT mode (never packed)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) {
-                    const int row = em0 + mt * 32 + l31;
-                    const bool ok = row < g.rvalid, okm = ok && row >= 1 && 2 * row != g.Rn;
-                    const long ro = (long)row * g.ldc, rm = (long)(g.Rn - row) * g.ldc;
+                for (int hr = 0; hr <= 16; ++hr) {
+                    if (hr < 16) {                                 // write half-round hr: block mt, rows 16 half + (0..15), output o
+                        const int mt = hr >> 2, half = (hr >> 1) & 1, o = hr & 1;
+                        float *w = stg + (hr & 1) * 512 + (4 * h) * 32 + l31;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const bool v2 = packed && q >= 2;                       // second variant: products swapped (see dft_rx3.hip)
-                        const float e00 = v2 ? g.e_alt[1] : g.e00, e01 = v2 ? g.e_alt[0] : g.e01;
-                        const float e10 = v2 ? g.e_alt[3] : g.e10, e11 = v2 ? g.e_alt[2] : g.e11;
-                        const int col = packed ? cw * 16 + 8 * (q & 1) + 4 * h : cw * 32 + 8 * q + 4 * h;
-                        float *d0 = (v2 ? DA : D0) + col;
-                        const float a0 = acc1[mt][4 * q], a1 = acc1[mt][4 * q + 1], a2 = acc1[mt][4 * q + 2], a3 = acc1[mt][4 * q + 3];
-                        const float b0 = acc2[mt][4 * q], b1 = acc2[mt][4 * q + 1], b2 = acc2[mt][4 * q + 2], b3 = acc2[mt][4 * q + 3];
-                        if (WS_EXP & 4) {
-                            asm volatile("" ::"v"(a0), "v"(a1), "v"(a2), "v"(a3), "v"(b0), "v"(b1), "v"(b2), "v"(b3));
-                        } else if (g.mode == 0) {
-                            if (ok) *reinterpret_cast<float4 *>(d0 + ro) = make_float4(e00 * a0 + e01 * b0, e00 * a1 + e01 * b1, e00 * a2 + e01 * b2, e00 * a3 + e01 * b3);
-                            if (okm) *reinterpret_cast<float4 *>(d0 + rm) = make_float4(e10 * a0 + e11 * b0, e10 * a1 + e11 * b1, e10 * a2 + e11 * b2, e10 * a3 + e11 * b3);
-                        } else {
-                            if (ok) {
-                                *reinterpret_cast<float4 *>(D0 + col + ro) = make_float4(e00 * a0, e00 * a1, e00 * a2, e00 * a3);
-                                *reinterpret_cast<float4 *>(D1 + col + ro) = make_float4(e11 * b0, e11 * b1, e11 * b2, e11 * b3);
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const float a1 = acc1[mt][8 * half + rr], a2 = acc2[mt][8 * half + rr];
+                            float v;
+                            if (g.mode == 0) v = o ? (e10 * a1 + e11 * a2) : (e00 * a1 + e01 * a2);
+                            else v = o ? (e11 * a2) : (e00 * a1);
+                            w[((rr & 3) + 8 * (rr >> 2)) * 32] = v;
+                        }
+                    }
+                    if (hr > 0) {                                  // read half-round hr - 1 back as rows and store them
+                        const int q = hr - 1, mt = q >> 2, half = (q >> 1) & 1, o = q & 1;
+                        const float *rd = stg + (q & 1) * 512 + rrow * 32 + 4 * cg;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float4 v = *reinterpret_cast<const float4 *>(rd + i * 256);
+                            const int row = em0 + mt * 32 + 16 * half + 8 * i + rrow;
+                            if (WS_EXP & 4) {
+                                asm volatile("" ::"v"(v.x), "v"(v.y), "v"(v.z), "v"(v.w));
+                            } else if (g.mode == 0) {
+                                if (o == 0) {
+                                    if (row < g.rvalid) *reinterpret_cast<float4 *>(Dv + (long)row * g.ldc) = v;
+                                } else {
+                                    if (row < g.rvalid && row >= 1 && 2 * row != g.Rn) *reinterpret_cast<float4 *>(Dv + (long)(g.Rn - row) * g.ldc) = v;
+                                }
+                            } else {
+                                if (row < g.rvalid) *reinterpret_cast<float4 *>((o ? D1 : Dv) + (long)row * g.ldc) = v;
                             }
                         }
                     }
                 }
             }
-            if (s + 1 < S) WS_BARRIER();
-            kt = nkt;
-            ti = nti;
+            if (s + 1 < S) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                WS_BARRIER();
+            }
+            if (++kt == nk) { kt = 0; ++ti; }
         }
-#undef WS_DMA
-#undef WS_MIXDMA
         return;
     }
 
     // ================================================================== producers
+    const int pw = wave - 4, ptid = tid - 256;
     const int kin = g.Kn / 2 + 1;
-    float rx[RING][8], ri[RING][8], rq[RING][8], rp[RING][8];     // raw rows (stream 0 / 1) and their mirror rows, per ring slot
     float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);                   // template weights of the lane's column (MIX)
     int hv = h;
+    const unsigned ldb4 = (unsigned)(g.ldb * 4), c4 = (unsigned)lcol * 4u;
+    const long ldbB = g.ldb * 4;
+    // matrix tiles: position 2*row + c of a piece holds the k-half c ^ ((row >> 3) & 1) of the row, which makes the fragment
+    // reads (ds_read_b128, 16-lane groups) conflict-free.  Producer wave pw fills rows 32 pw .. 32 pw + 31, lane-linear.
+    const int amrow = ptid >> 1;
+    const unsigned aoff = (unsigned)(amrow * g.lda + 8 * ((lane & 1) ^ ((amrow >> 3) & 1))) * 2u;
 
-    // load cursor: k-step lstep of this workgroup's stream = k-step lkt of local tile li; it stops at the last step (the loads
-    // behind the end of the stream repeat that step: no branch around a vector load, so the compiler keeps counted waits)
-    int li = 0, lkt = 0, lstep = 0;
+    // Three register sets; set f % 3 holds what body f needs -- the lane's 8 (+ 8 mirror) raw rows of k-step f (k = 16 kt + 8 h + j,
+    // straight from HBM: consecutive lanes are consecutive columns, every instruction two 128-byte segments), the lane's 16
+    // bytes x 6 of the matrix tile, the template weights of its column -- and is refilled for k-step f + 3 at the end of that body
+    // (plain loads: the compiler counts them, the other two sets' stay in flight).  Behind the end of the stream the cursor stops.
+    float rx0[8], ri0[8], rq0[8], rp0[8], rx1[8], ri1[8], rq1[8], rp1[8], rx2[8], ri2[8], rq2[8], rp2[8];
+    f32x4 stw0, stw1, stw2;
+    u32x4 sA0[6], sA1[6], sA2[6];
+    int li = 0, lkt = 0, lstep = 0;                                // load cursor: k-step lstep = k-step lkt of local tile li
     const char *LB0 = nullptr, *LB1 = nullptr;
+    const char *LA0 = nullptr, *LA1 = nullptr;
+    int ln0 = 0;
 #define WS_LSETUP()                                                                                                 \
     {                                                                                                               \
-        const int t_ = (int)blockIdx.x + li * (int)gridDim.x;                                                       \
-        const long bz_ = t_ / (tilesX * tilesY);                                                                    \
-        const int n0_ = (t_ % tilesX) * TN;                                                                         \
-        LB0 = reinterpret_cast<const char *>(g.src[0] + bz_ * g.sB + n0_);                                          \
-        LB1 = reinterpret_cast<const char *>(g.src[1] + bz_ * g.sB + n0_);                                          \
+        const long t_ = t0 + li;                                                                                    \
+        const long bz_ = t_ / ((long)tilesX * tilesY);                                                              \
+        const int m0_ = (int)((t_ / tilesX) % tilesY) * 128;                                                        \
+        ln0 = (int)(t_ % tilesX) * TN;                                                                              \
+        LB0 = reinterpret_cast<const char *>(g.src[0] + bz_ * g.sB + ln0);                                          \
+        LB1 = reinterpret_cast<const char *>(g.src[1] + bz_ * g.sB + ln0);                                          \
+        LA0 = reinterpret_cast<const char *>(g.A[0] + (long)m0_ * g.lda) + aoff;                                    \
+        LA1 = reinterpret_cast<const char *>(g.A[1] + (long)m0_ * g.lda) + aoff;                                    \
     }
-    // raw loads of this lane's 8 k of k-step lkt (k = 16 kt + 8 h + j) and of their mirror rows; branch-free so that all of
-    // them are in flight together.  Row part of every address in 64-bit scalar pointers, lane part in one small VGPR.
-    // Mirror row of k is (Kn - 16 kt - 8 - j) + 8 (1 - h); read unconditionally (its weight is zero where there is no mirror),
-    // except k = 0 whose "mirror" Kn may not exist.
-#define WS_LOAD(r_)                                                                                                 \
+    // Row part of every address in 64-bit scalar pointers, lane part in one small VGPR.  Mirror row of k is
+    // (Kn - 16 kt - 8 - j) + 8 (1 - h); read unconditionally (its weight is zero where there is no mirror), except k = 0 whose
+    // "mirror" Kn may not exist.
+#define WS_LOAD(x_)                                                                                                 \
     {                                                                                                               \
         const char *rk0 = LB0 + (long)(lkt * BK) * ldbB, *rk1 = LB1 + (long)(lkt * BK) * ldbB;                      \
-        const char *rp0 = LB0 + (long)(g.Kn - lkt * BK - 8) * ldbB, *rp1 = LB1 + (long)(g.Kn - lkt * BK - 8) * ldbB; \
+        const char *rp0_ = LB0 + (long)(g.Kn - lkt * BK - 8) * ldbB, *rp1_ = LB1 + (long)(g.Kn - lkt * BK - 8) * ldbB; \
         const unsigned vk = (unsigned)(8 * hv) * ldb4 + c4, vp = (unsigned)(8 * (1 - hv)) * ldb4 + c4;              \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
-            if (WS_EXP & 1) { rx[r_][j] = ri[r_][j] = rq[r_][j] = rp[r_][j] = (float)(lstep + j); continue; }     \
-            rx[r_][j] = *reinterpret_cast<const float *>(rk0 + j * ldbB + vk);                                     \
-            if (KIND != 1) ri[r_][j] = *reinterpret_cast<const float *>(rk1 + j * ldbB + vk);                      \
+            if (WS_EXP & 1) { rx##x_[j] = ri##x_[j] = rq##x_[j] = rp##x_[j] = (float)(lstep + j); continue; }       \
+            rx##x_[j] = WS_GLOBAL(float, rk0 + j * ldbB + vk);                                                      \
+            if (KIND != 1) ri##x_[j] = WS_GLOBAL(float, rk1 + j * ldbB + vk);                                       \
             if (KIND != 2) {                                                                                       \
                 const unsigned q = (j == 0 && lkt == 0) ? c4 : vp;                                                 \
-                rq[r_][j] = *reinterpret_cast<const float *>(rp0 - j * ldbB + q);                                  \
-                if (KIND != 1) rp[r_][j] = *reinterpret_cast<const float *>(rp1 - j * ldbB + q);                   \
+                rq##x_[j] = WS_GLOBAL(float, rp0_ - j * ldbB + q);                                                  \
+                if (KIND != 1) rp##x_[j] = WS_GLOBAL(float, rp1_ - j * ldbB + q);                                   \
             }                                                                                                      \
         }                                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                            \
+            sA##x_[q] = (WS_EXP & 32) ? u32x4{(unsigned)q, 1u, 2u, 3u} : WS_GLOBAL(u32x4, LA0 + 2 * q * g.planeA + (unsigned)(lkt * BK) * 2u); \
+            sA##x_[3 + q] = (WS_EXP & 32) ? u32x4{(unsigned)q, 4u, 5u, 6u} : WS_GLOBAL(u32x4, LA1 + 2 * q * g.planeA + (unsigned)(lkt * BK) * 2u); \
+        }                                                                                                          \
+        if (MIX) stw##x_ = WS_GLOBAL(f32x4, g.tplT + ln0 % g.LP + lcol);                                            \
         if (lstep + 1 < S) {                                                                                       \
             ++lstep;                                                                                               \
             if (++lkt == nk) { lkt = 0; ++li; WS_LSETUP(); }                                                       \
         }                                                                                                          \
     }
-    // fold (and mix) ring slot r_ = k-step fkt of tile fi into the two data streams, split, store as B fragments of stage st_
-#define WS_FOLD(r_, st_)                                                                                            \
+#define WS_A_WRITE(x_, step_)                                                                                       \
     {                                                                                                               \
-        const float4 *mb = mtab + (fi & 1) * mixs;                                                                  \
-        if (MIX && fkt == 0) tw = mb[mixn + lcol];                                                                  \
+        u32x4 *lb = reinterpret_cast<u32x4 *>(ldsA + ((step_) & 1) * ABUF + pw * 512) + lane;                       \
+        _Pragma("unroll") for (int q = 0; q < 3; ++q) {                                                            \
+            lb[q * (PIECE / 8)] = sA##x_[q];                                                                       \
+            lb[(IMG + q * PIECE) / 8] = sA##x_[3 + q];                                                             \
+        }                                                                                                          \
+    }
+    // spectral-mix table of local tile i_'s k_beta ([k][re/im] x 4 templates, laid out by mix_table_kernel): global -> LDS
+#define WS_MIXTAB_LOAD(i_)                                                                                          \
+    {                                                                                                               \
+        const float4 *src = g.mixtab + (long)kb_of(i_) * mixn;                                                      \
+        for (int e = ptid; e < mixn; e += 256) {                                                                    \
+            const f32x4 v_ = WS_GLOBAL(f32x4, src + e);                                                             \
+            *reinterpret_cast<f32x4 *>(mtab + e) = v_;                                                              \
+        }                                                    \
+    }
+    // fold (and mix) the raw rows of k-step fkt of tile fi (LDS stage rs_) into the two data streams, split, store as B fragments
+#define WS_FOLD(x_, st_)                                                                                            \
+    {                                                                                                               \
         float x0[8], x1[8];                                                                                         \
         _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                            \
             const int k = fkt * BK + 8 * hv + j;                                                                    \
-            float ar = rx[r_][j], ai = (KIND == 1) ? rx[r_][j] : ri[r_][j];                                         \
+            float ar = rx##x_[j], ai_ = (KIND == 1) ? rx##x_[j] : ri##x_[j];                                        \
+            float br = (KIND == 2) ? 0.f : rq##x_[j], bi = (KIND == 2) ? 0.f : (KIND == 1) ? rq##x_[j] : rp##x_[j]; \
             if (MIX) {                                                                                             \
-                const float4 mr = mb[2 * k], mi = mb[2 * k + 1];                                                   \
+                const float4 mr = mtab[2 * k], mi = mtab[2 * k + 1];                                               \
                 const float sr = tw.x * mr.x + tw.y * mr.y + tw.z * mr.z + tw.w * mr.w;                            \
                 const float si = tw.x * mi.x + tw.y * mi.y + tw.z * mi.z + tw.w * mi.w;                            \
-                const float hr = ar, hi = ai;                                                                      \
+                const float hr = ar, hi = ai_;                                                                     \
                 ar = hr * sr - hi * si;                                                                            \
-                ai = hr * si + hi * sr;                                                                            \
+                ai_ = hr * si + hi * sr;                                                                           \
             }                                                                                                      \
             if (KIND == 2) {                                                                                       \
                 x0[j] = ar;                                                                                        \
-                x1[j] = ai;                                                                                        \
+                x1[j] = ai_;                                                                                       \
             } else {                                                                                               \
                 const bool pv = (k >= 1) && (k < kin) && (2 * k != g.Kn);                                          \
-                float br = rq[r_][j], bi = (KIND == 1) ? rq[r_][j] : rp[r_][j];                                     \
                 if (MIX) {                                                                                         \
                     const int kp = pv ? g.Kn - k : k;                                                              \
-                    const float4 mr = mb[2 * kp], mi = mb[2 * kp + 1];                                             \
+                    const float4 mr = mtab[2 * kp], mi = mtab[2 * kp + 1];                                         \
                     const float sr = tw.x * mr.x + tw.y * mr.y + tw.z * mr.z + tw.w * mr.w;                        \
                     const float si = tw.x * mi.x + tw.y * mi.y + tw.z * mi.z + tw.w * mi.w;                        \
                     const float hr = br, hi = bi;                                                                  \
@@ -327,55 +337,68 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
                 const float g0 = var ? g.fold_alt[0] : g.fold[0], g1 = var ? g.fold_alt[1] : g.fold[1];            \
                 const float f0 = pv ? g0 : 0.f, f1 = pv ? g1 : 0.f;                                                \
                 const float w0 = (!pv && g0 < 0.f) ? 0.f : 1.f, w1 = (!pv && g1 < 0.f) ? 0.f : 1.f;                \
-                const float s0 = w0 * ar + f0 * br, s1v = w1 * ai + f1 * bi;                                       \
+                const float s0 = w0 * ar + f0 * br, s1v = w1 * ai_ + f1 * bi;                                      \
                 x0[j] = var ? s1v : s0;       /* the second variant pairs its streams with the other matrix */      \
                 x1[j] = var ? s0 : s1v;                                                                            \
             }                                                                                                      \
         }                                                                                                          \
         uint4 f0h, f0m, f0l, f1h, f1m, f1l;                                                                        \
         if (WS_EXP & 8) {                                                                                          \
-            f0h = make_uint4(__float_as_uint(rx[r_][0]), __float_as_uint(rx[r_][1]), __float_as_uint(rx[r_][2]), __float_as_uint(rx[r_][3])); \
-            f0m = make_uint4(__float_as_uint(rx[r_][4]), __float_as_uint(rx[r_][5]), __float_as_uint(rx[r_][6]), __float_as_uint(rx[r_][7])); \
-            f0l = f0h; f1h = f0m; f1m = f0h; f1l = f0m;                                                            \
-            if (KIND != 1) { f1h.x ^= __float_as_uint(ri[r_][0] + ri[r_][1] + ri[r_][2] + ri[r_][3] + ri[r_][4] + ri[r_][5] + ri[r_][6] + ri[r_][7]); } \
-            if (KIND != 2) { f1m.x ^= __float_as_uint(rq[r_][0] + rq[r_][1] + rq[r_][2] + rq[r_][3] + rq[r_][4] + rq[r_][5] + rq[r_][6] + rq[r_][7]); } \
-            if (KIND == 0) { f1l.x ^= __float_as_uint(rp[r_][0] + rp[r_][1] + rp[r_][2] + rp[r_][3] + rp[r_][4] + rp[r_][5] + rp[r_][6] + rp[r_][7]); } \
+            f0h = make_uint4(__float_as_uint(x0[0]), __float_as_uint(x0[1]), __float_as_uint(x0[2]), __float_as_uint(x0[3])); \
+            f0m = make_uint4(__float_as_uint(x0[4]), __float_as_uint(x0[5]), __float_as_uint(x0[6]), __float_as_uint(x0[7])); \
+            f1h = make_uint4(__float_as_uint(x1[0]), __float_as_uint(x1[1]), __float_as_uint(x1[2]), __float_as_uint(x1[3])); \
+            f1m = make_uint4(__float_as_uint(x1[4]), __float_as_uint(x1[5]), __float_as_uint(x1[6]), __float_as_uint(x1[7])); \
+            f0l = f0h; f1l = f1h;                                                                                  \
         } else {                                                                                                   \
-        split8(x0, f0h, f0m, f0l);                                                                                  \
-        split8(x1, f1h, f1m, f1l);                                                                                  \
+            split8(x0, f0h, f0m, f0l);                                                                              \
+            split8(x1, f1h, f1m, f1l);                                                                              \
         }                                                                                                          \
         uint4 *wb = reinterpret_cast<uint4 *>(ldsB + (st_) * BBUF + cw * BWAVE) + lane;                            \
         wb[0] = f0h; wb[64] = f0m; wb[128] = f0l; wb[192] = f1h; wb[256] = f1m; wb[320] = f1l;                     \
+    }
+    // body f (beside the consumers' k-step f - 1): register set x_ = f & 1 -> LDS (raw rows of k-step f + 1, matrix tile of
+    // k-step f), refill it (k-steps f + 3 / f + 2), fold k-step f
+#define WS_BODY(x_, p_)                                                                                               \
+    {                                                                                                               \
+        if (MIX && fkt == 0 && fi > 0 && kb_of(fi) != kb_of(fi - 1)) {                                              \
+            /* another k_beta: every wave has left the old table behind (previous barrier); fetch the new one, publish it */ \
+            WS_MIXTAB_LOAD(fi);                                                                                     \
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                      \
+            WS_BARRIER();                                                                                           \
+        }                                                                                                          \
+        if (MIX && fkt == 0) tw = make_float4(stw##x_[0], stw##x_[1], stw##x_[2], stw##x_[3]);                      \
+        WS_A_WRITE(x_, f);                                                                                          \
+        WS_FOLD(x_, f & 1);                                                                                         \
+        WS_LOAD(x_);                                                                                                \
         if (++fkt == nk) { fkt = 0; ++fi; }                                                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                          \
+        WS_BARRIER();                                                                                               \
+        ++f;                                                                                                        \
     }
 
-    // ---- slot -2: the first RING k-steps of loads in flight
+    // ---- prologue: sets 0 / 1 / 2 <- k-steps 0 / 1 / 2; the mix table of tile 0 into LDS
     WS_LSETUP();
-#pragma unroll
-    for (int r = 0; r < RING; ++r) WS_LOAD(r);
+    WS_LOAD(0);
+    WS_LOAD(1);
+    WS_LOAD(2);
+    if (MIX) WS_MIXTAB_LOAD(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     WS_BARRIER();
-    // ---- slots -1 .. S-2: in slot f - 1 fold k-step f (ring slot f % RING), then refill that ring slot with k-step f + RING
-    int fi = 0, fkt = 0, f0 = 0;
-    for (; f0 + RING <= S; f0 += RING) {
+    int fi = 0, fkt = 0, f = 0;
+    while (f + 3 <= S) {
         asm volatile("" : "+v"(hv));   // keeps the per-lane fold selectors from being hoisted out of the loop
-#pragma unroll
-        for (int r = 0; r < RING; ++r) {
-            WS_FOLD(r, (f0 + r) & 1);
-            WS_LOAD(r);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            WS_BARRIER();
-        }
+        WS_BODY(0, 0)
+        WS_BODY(1, 1)
+        WS_BODY(2, 2)
     }
-#pragma unroll
-    for (int r = 0; r < RING - 1; ++r)      // the last S % RING k-steps: nothing left to load
-        if (f0 + r < S) {
-            WS_FOLD(r, (f0 + r) & 1);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            WS_BARRIER();
-        }
+    if (f < S) WS_BODY(0, 0)
+    if (f < S) WS_BODY(1, 1)
 #undef WS_LSETUP
 #undef WS_LOAD
+#undef WS_A_WRITE
+#undef WS_MIXTAB_LOAD
 #undef WS_FOLD
+#undef WS_BODY
 }
 
 }  // namespace
@@ -386,15 +409,19 @@ bool dft_ws_can(const DftRx3Args &g) {
     if (g.nvar != 1 && !(g.nvar == 2 && g.packed)) return false;
     const bool folded = g.fold[0] != 0.f || g.fold[1] != 0.f || (g.nvar == 2 && (g.fold_alt[0] != 0.f || g.fold_alt[1] != 0.f));
     const int kind = !folded ? 2 : (g.src[0] == g.src[1] ? 1 : 0);
+    if (kind != 2 && (g.Kn < 2 || g.KP > g.Kn + 16)) return false;     // folded: mirror rows Kn - k of every k < KP exist (clamped at 0)
+    if (kind == 0 && g.nvar != 2) return false;       // the complex pass is built in its packed form only
+    if (kind != 0 && g.nvar != 1) return false;
+    if ((long)g.ldb % 4 || (long)g.ldc % 4 || (long)g.sB % 4 || (long)g.sC % 4) return false;     // 16-byte DMA and float4 stores
     if (g.nvar == 2) {
-        const long dalt = g.dst_alt ? (long)(g.dst_alt - g.dst[0]) * 4 : -1;
-        if (kind != 0 || g.mode != 0 || g.N % 64 || dalt < 0 || dalt >= 2147483648L || !g.A_alt[0]) return false;
+        const long dalt = g.dst_alt ? (long)(g.dst_alt - g.dst[0]) : -1;
+        if (g.mode != 0 || g.N % 64 || dalt < 0 || dalt % 4 || !g.A_alt[0]) return false;
         // the packed form keeps A[0], A[1] for both variants: the second variant's matrices must be the first one's, swapped
         if (g.A_alt[0] != g.A[1] || g.A_alt[1] != g.A[0]) return false;
     } else if (g.N % 128) return false;
     if (g.mhat) {      // fused spectral mix: needs the table built by launch_dft_ws_mix_table and whole-DMA table sizes
-        if (kind != 0 || g.nvar != 2 || g.LP % 128 || g.T < 1 || g.T > 4 || g.KP / BK < 3 || !g.mixtab || !g.tplT ||
-            g.mix_rows % 32 || g.mix_rows < g.Kn || g.mix_rows < g.KP || g.mix_rows > MIX_ROWS_MAX)
+        if (kind != 0 || g.LP % 64 || g.T < 1 || g.T > 4 || g.KP / BK < 2 || !g.mixtab || !g.tplT ||
+            g.mix_rows % 128 || g.mix_rows < g.Kn || g.mix_rows < g.KP || g.mix_rows > MIX_ROWS_MAX)
             return false;
     }
     return true;
@@ -403,7 +430,6 @@ bool dft_ws_can(const DftRx3Args &g) {
 int launch_dft_ws(hipStream_t stream, const DftRx3Args &g) {
     if (!dft_ws_can(g)) return (int)hipErrorInvalidValue;
     if (g.mode == 1 && !g.dst[1]) return (int)hipErrorInvalidValue;
-    if (8.0 * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0 || 4.0 * (double)g.ldc * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
     const bool folded = g.fold[0] != 0.f || g.fold[1] != 0.f || (g.nvar == 2 && (g.fold_alt[0] != 0.f || g.fold_alt[1] != 0.f));
     const int kind = !folded ? 2 : (g.src[0] == g.src[1] ? 1 : 0);
     static int cus_of[64] = {0};
@@ -419,10 +445,10 @@ int launch_dft_ws(hipStream_t stream, const DftRx3Args &g) {
     a.strided = 0;
     const long ntile = (long)(g.N / (a.packed ? 64 : 128)) * (g.MP / 128) * g.batch;
     dim3 grid((unsigned)(ntile < cus_of[dev] ? ntile : cus_of[dev]));
-    const size_t mix_bytes = g.mhat ? (size_t)2 * (2 * g.mix_rows + 128) * sizeof(float4) : 0;
+    const size_t mix_bytes = g.mhat ? (size_t)2 * g.mix_rows * sizeof(float4) : 0;
     static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
     if (g.mhat) {
-        if (int e = ensure_dynamic_lds(dft_ws_kernel<0, true>, LDS_MAIN + (size_t)2 * (2 * MIX_ROWS_MAX + 128) * sizeof(float4), d3)) return e;
+        if (int e = ensure_dynamic_lds(dft_ws_kernel<0, true>, LDS_MAIN + (size_t)2 * MIX_ROWS_MAX * sizeof(float4), d3)) return e;
         hipLaunchKernelGGL((dft_ws_kernel<0, true>), grid, dim3(512), LDS_MAIN + mix_bytes, stream, a);
     } else if (kind == 0) {
         if (int e = ensure_dynamic_lds(dft_ws_kernel<0, false>, LDS_MAIN, d0)) return e;
@@ -455,10 +481,10 @@ __global__ __launch_bounds__(256) void mix_table_kernel(const float *__restrict_
 }
 }  // namespace
 
-int dft_ws_mix_rows(int Kn, int KP) { return ((Kn > KP ? Kn : KP) + 31) / 32 * 32; }
+int dft_ws_mix_rows(int Kn, int KP) { return ((Kn > KP ? Kn : KP) + 127) / 128 * 128; }
 
 int launch_dft_ws_mix_table(hipStream_t stream, const float *mhat, float *mixtab, int T, int Kn, int nkb, long PL, long KBP, int mix_rows) {
-    if (T < 1 || T > 4 || nkb < 1 || mix_rows < Kn || mix_rows % 32) return (int)hipErrorInvalidValue;
+    if (T < 1 || T > 4 || nkb < 1 || mix_rows < Kn || mix_rows % 128) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)((nkb + 63) / 64), (unsigned)((2 * mix_rows + 3) / 4));
     hipLaunchKernelGGL(mix_table_kernel, grid, dim3(256), 0, stream, mhat, reinterpret_cast<float4 *>(mixtab), T, Kn, nkb, PL, KBP, mix_rows);
     return (int)hipGetLastError();
