@@ -46,17 +46,6 @@ struct DftRx3Args {
     const float *mhat = nullptr, *tpl = nullptr;   // optional fused spectral mix
     int T = 0, LP = 0;
     long PL = 0, KBP = 0;
-    // wave-specialised kernel only: the same mix as per-tile tables it can move to LDS by DMA --
-    // mixtab[kb][2 k + c] = (mhat[t][c][k][kb])_t (launch_dft_ws_mix_table, mix_rows = dft_ws_mix_rows(Kn, KP) rows k, zero
-    // beyond Kn) and tplT[l] = (tpl[t][l])_t
-    const float4 *mixtab = nullptr, *tplT = nullptr;
-    int mix_rows = 0;
 };
 int launch_dft_rx3(hipStream_t stream, const DftRx3Args &g);
-// the same pass on the wave-specialised kernel (dft_ws.hip): producer waves load / fold / split, consumer waves only feed the
-// matrix cores.  dft_ws_can() says whether it covers the arguments (otherwise use launch_dft_rx3).
-bool dft_ws_can(const DftRx3Args &g);
-int launch_dft_ws(hipStream_t stream, const DftRx3Args &g);
-int dft_ws_mix_rows(int Kn, int KP);
-int launch_dft_ws_mix_table(hipStream_t stream, const float *mhat, float *mixtab, int T, int Kn, int nkb, long PL, long KBP, int mix_rows);
 bool dft_rx3_supported(int Na, int Nb, long NAP, long KBP, long LP);

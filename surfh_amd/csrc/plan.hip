@@ -147,7 +147,6 @@ struct surfh_plan {
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
     int n_cu = 256;
     int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
-    bool dft_ws = true;                          // DFT passes on the wave-specialised kernel (dft_ws.hip); SURFH_DFT_WS=0: dft_rx3.hip
     bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
     bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
     bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
@@ -159,8 +158,6 @@ struct surfh_plan {
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
-    float *mixtab = nullptr, *tplT = nullptr;    // fused spectral mix of the wave-specialised pass: [hb][2 mix_rows] x 4 and [LP] x 4 (dft_rx3.h)
-    int mix_rows = 0;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
     // CG
@@ -717,12 +714,6 @@ int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
 
 // ---- the same two transforms with the symmetry-folded kernel (dft_fold.h): 3x fewer flops --------
 // ---- split-bf16, register-direct variant of the folded passes (dft_rx3.h) ------------------------
-// one pass on the wave-specialised kernel where it covers the shape (default), else on the one-role kernel
-int launch_dft_pass(surfh_plan *p, const DftRx3Args &g) {
-    if (p->dft_ws && dft_ws_can(g)) return launch_dft_ws(p->stream, g);
-    return launch_dft_rx3(p->stream, g);
-}
-
 int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -734,7 +725,7 @@ int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
     g.MP = p->MPb; g.KP = p->KPb; g.N = (int)(p->Na * LP);
     {
         Prof pr(p, "dft_rx3_rows_fwd");
-        LAUNCH_OK(launch_dft_pass(p, g));
+        LAUNCH_OK(launch_dft_rx3(p->stream, g));
     }
     {   // c2c along alpha, batched over k_beta; both output components of a tile back to back (second read from cache)
         DftRx3Args h;
@@ -748,7 +739,7 @@ int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
         h.A_alt[0] = p->Sma3; h.A_alt[1] = p->Cma3; h.fold_alt[0] = -1.f; h.fold_alt[1] = 1.f; h.dst_alt = dst + p->PL * LP;
         h.e_alt[0] = -1.f; h.e_alt[1] = 1.f; h.e_alt[2] = 1.f; h.e_alt[3] = 1.f;
         Prof pr(p, "dft_rx3_cols_fwd");
-        LAUNCH_OK(launch_dft_pass(p, h));
+        LAUNCH_OK(launch_dft_rx3(p->stream, h));
     }
     return 0;
 }
@@ -768,19 +759,9 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
         g.A_alt[0] = p->Sma3; g.A_alt[1] = p->Cma3; g.fold_alt[0] = -1.f; g.fold_alt[1] = 1.f;
         g.dst_alt = p->ycol + (long)p->NAP * p->KBP * LP;
         g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = -1.f; g.e_alt[3] = 1.f;
-        if (mix) {
-            g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP;
-            if (p->dft_ws && p->mixtab) {     // the wave-specialised kernel takes the mix as per-tile tables it moves to LDS by DMA
-                g.mixtab = reinterpret_cast<const float4 *>(p->mixtab); g.tplT = reinterpret_cast<const float4 *>(p->tplT);
-                g.mix_rows = p->mix_rows;
-                if (dft_ws_can(g)) {
-                    Prof pr(p, "mix_table");
-                    LAUNCH_OK(launch_dft_ws_mix_table(p->stream, p->mhat, p->mixtab, p->T, p->Na, hb, p->PL, p->KBP, p->mix_rows));
-                }
-            }
-        }
+        if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
         Prof pr(p, mix ? "dft_rx3_cols_inv_mix" : "dft_rx3_cols_inv");
-        LAUNCH_OK(launch_dft_pass(p, g));
+        LAUNCH_OK(launch_dft_rx3(p->stream, g));
     }
     DftRx3Args h;   // c2r along beta, batched over alpha
     h.A[0] = p->Gc3; h.A[1] = p->Gs3; h.planeA = (long)p->MPb * p->KPb; h.lda = p->KPb;
@@ -790,7 +771,7 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
     h.MP = p->MPb; h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
     {
         Prof pr(p, "dft_rx3_rows_inv");
-        LAUNCH_OK(launch_dft_pass(p, h));
+        LAUNCH_OK(launch_dft_rx3(p->stream, h));
     }
     return 0;
 }
@@ -1091,7 +1072,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipSetDevice(p->dev);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
-                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->mixtab, p->tplT, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
+                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
         hipFree(v);
     hipFree(p->dft3);
     hipFree(p->dscal);
@@ -1251,8 +1232,6 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         const char *e7 = getenv("SURFH_OVERLAP");
         p->overlap = e7 && e7[0] == '1';
         if (p->overlap && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
-        const char *e16 = getenv("SURFH_DFT_WS");
-        p->dft_ws = !(e16 && e16[0] == '0');
         const char *e8 = getenv("SURFH_DFT_PACKED");
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e6 = getenv("SURFH_WBLUR_PC");
@@ -1324,14 +1303,6 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             p->Cma3 = p->dft3 + off[0]; p->Sma3 = p->dft3 + off[1]; p->Gc3 = p->dft3 + off[2];
             p->Gs3 = p->dft3 + off[3]; p->Cf3 = p->dft3 + off[4]; p->Sf3 = p->dft3 + off[5];
         }
-    }
-    if (p->T > 0 && p->T <= 4 && p->rx3 && p->dft_ws) {   // tables of the fused spectral mix (wave-specialised pass)
-        p->mix_rows = dft_ws_mix_rows(p->Na, p->KPa);
-        std::vector<float> tT((size_t)LP * 4, 0.f);
-        for (int k = 0; k < p->T; ++k)
-            for (int l = 0; l < p->Lown; ++l)
-                if (p->planes[l] >= 0) tT[(size_t)l * 4 + k] = (float)cfg->templates[(size_t)k * p->Lc + p->planes[l]];
-        if (dev_upload(&p->tplT, tT) || dev_alloc(&p->mixtab, (size_t)(p->Nb / 2 + 1) * 2 * p->mix_rows * 4)) return bail(1);
     }
     // ---- work buffers ---------------------------------------------------------------------
     const size_t nspec = (size_t)2 * p->PL * LP, ncube = (size_t)p->NBP * p->NAP * LP;

@@ -1,4 +1,6 @@
-// Wave-specialised form of the split-bf16 folded DFT pass (arithmetic, operand layout and arguments of dft_rx3.h).
+// EXPERIMENT (not part of the product library; see README.md here): wave-specialised form of the split-bf16 folded DFT pass
+// (arithmetic, operand layout and arguments of surfh_amd/csrc/dft_rx3.h).  Correct (it passed tests/test_gpu_parity.py as the
+// product path), but no faster than dft_rx3.hip: 0.58-0.92 ms per pass on config 3 against 0.48-0.79.
 //
 // One persistent workgroup of 8 waves per CU walks a contiguous range of tiles; a tile is 128 output rows x 128 columns
 // (lambda), 64 columns for the packed complex pass.  Waves 4-7 are PRODUCERS, waves 0-3 CONSUMERS; wave w + 4 and wave w share a
@@ -20,8 +22,8 @@
 //     accumulators through the (just consumed) B-fragment stage of the wave to turn "lane = column" into 16-byte rows:
 //     32 float4 stores per lane and tile (eight 128-byte row segments per instruction) instead of 128 one-dword stores, which
 //     queue (< 63 outstanding) and drain while the next tile is computed.
-#include "dft_rx3.h"
-#include "lds_attr.h"
+#include "dft_ws.h"
+#include "../../surfh_amd/csrc/lds_attr.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -106,7 +108,7 @@ __device__ __forceinline__ void split8(const float (&x)[8], uint4 &fh, uint4 &fm
 // KIND 0: two source streams, folded, PACKED (complex pass, both output components from one read of a 64-column tile);
 //      1: one real source feeding both streams (r2c); 2: two streams, no fold (c2r).
 template <int KIND, bool MIX>
-__global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
+__global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftWsArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -404,7 +406,7 @@ __global__ __launch_bounds__(512, 2) void dft_ws_kernel(DftRx3Args g) {
 }  // namespace
 
 // Whether launch_dft_ws can run this pass (the callers fall back to launch_dft_rx3 otherwise)
-bool dft_ws_can(const DftRx3Args &g) {
+bool dft_ws_can(const DftWsArgs &g) {
     if (g.MP % 128 || g.KP % BK || g.batch < 1) return false;
     if (g.nvar != 1 && !(g.nvar == 2 && g.packed)) return false;
     const bool folded = g.fold[0] != 0.f || g.fold[1] != 0.f || (g.nvar == 2 && (g.fold_alt[0] != 0.f || g.fold_alt[1] != 0.f));
@@ -427,7 +429,7 @@ bool dft_ws_can(const DftRx3Args &g) {
     return true;
 }
 
-int launch_dft_ws(hipStream_t stream, const DftRx3Args &g) {
+int launch_dft_ws(hipStream_t stream, const DftWsArgs &g) {
     if (!dft_ws_can(g)) return (int)hipErrorInvalidValue;
     if (g.mode == 1 && !g.dst[1]) return (int)hipErrorInvalidValue;
     const bool folded = g.fold[0] != 0.f || g.fold[1] != 0.f || (g.nvar == 2 && (g.fold_alt[0] != 0.f || g.fold_alt[1] != 0.f));
@@ -440,7 +442,7 @@ int launch_dft_ws(hipStream_t stream, const DftRx3Args &g) {
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
         cus_of[dev] = cus;
     }
-    DftRx3Args a = g;
+    DftWsArgs a = g;
     a.packed = (g.nvar == 2) ? 1 : 0;
     a.strided = 0;
     const long ntile = (long)(g.N / (a.packed ? 64 : 128)) * (g.MP / 128) * g.batch;

@@ -1,10 +1,10 @@
 // micro-benchmark of the wave-specialised DFT pass (surfh_amd/csrc/dft_ws.hip) against the one-role kernel (dft_rx3.hip):
-// the four passes of config 3 (251 x 251 x 4096 planes) on random data.  Build variants with -DWS_RING=n / -DWS_EXP=n.
+// the four passes of config 3 (251 x 251 x 4096 planes) on random data.  Build variants with -DWS_EXP=mask (see dft_ws.hip).
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../surfh_amd/csrc/dft_rx3.h"
+#include "dft_ws.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void fill_k(float *p, long n, unsigned seed) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -35,7 +35,7 @@ int main(int argc, char **argv) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const bool only_ws = getenv("ONLY_WS") != nullptr;
     for (int pass = 0; pass < 5; ++pass) {
-        DftRx3Args g;
+        DftWsArgs g;
         g.A[0] = A; g.A[1] = A + 3 * MP * KP; g.planeA = (long)MP * KP; g.lda = KP; g.MP = MP; g.KP = KP;
         const char *name = "";
         if (pass == 0) {          // r2c along beta
