@@ -87,6 +87,10 @@ typedef struct {
     int32_t device;                    /* HIP device ordinal                                        */
     void *stream;                      /* hipStream_t to run on, or NULL: the plan creates its own  */
     int32_t split_k_forward;           /* 0 = auto                                                  */
+    int32_t verify;                    /* 1 = verification plan: every long sum (DFT products, spectral blur, spectral mix,
+                                          gather / scatter rows) accumulated in float64 on plain vector kernels.  Same operator,
+                                          same fp32 storage, ~100x slower: for the strict dot test
+                                          (test/sandbox_dottest.py:16-27 with randn vectors), not for production. */
 } surfh_config;
 
 const char *surfh_last_error(void);

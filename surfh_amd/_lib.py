@@ -39,7 +39,7 @@ class Config(C.Structure):
         ("n_alpha", C.c_int32), ("n_beta", C.c_int32), ("n_lambda", C.c_int32), ("n_templates", C.c_int32),
         ("templates", c_double_p), ("sotf", c_double_p),
         ("n_channels", C.c_int32), ("channels", C.POINTER(ChannelDesc)),
-        ("device", C.c_int32), ("stream", C.c_void_p), ("split_k_forward", C.c_int32),
+        ("device", C.c_int32), ("stream", C.c_void_p), ("split_k_forward", C.c_int32), ("verify", C.c_int32),
     ]
 
 

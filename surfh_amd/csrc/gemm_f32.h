@@ -41,6 +41,8 @@ struct GemmArgs {
 
 // returns hipError_t as int; name is used by the profiler
 int launch_gemm_f32(hipStream_t stream, const GemmArgs &g);
+// the same product with float64 accumulation (plain vector arithmetic; surfh_config.verify)
+int launch_gemm_f64acc(hipStream_t stream, const GemmArgs &g);
 
 // C[M][N] = A[M][K] * B[N][K]^T on the bf16 matrix cores with exact 3-way operand splitting (fp32-accurate,
 // see gemm_bf16x3.hip).  B0/ldb describe B as [N][K]; M, N multiples of 128.

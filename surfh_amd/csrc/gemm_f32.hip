@@ -135,6 +135,73 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 #undef GEMM_LSTORE
 }  // namespace
 
+// ---- verification form: the same product (same GemmArgs) with every dot product accumulated in float64 --------------------
+// 64 x 64 tile, 256 threads, 4 x 4 outputs per thread, operands staged through LDS as fp32.  Slow on purpose-free terms: it
+// exists for surfh_config.verify (the strict dot test), not for speed.
+namespace {
+__global__ __launch_bounds__(256) void gemm_f64acc_kernel(GemmArgs g) {
+    __shared__ float As[64][BK + 1];
+    __shared__ float Bs[BK][64 + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tilesN = g.N / 64;
+    const int tm = blockIdx.x / tilesN, tn = blockIdx.x % tilesN;
+    const int b = blockIdx.z / g.splitK, sk = blockIdx.z % g.splitK;
+    const int m0 = tm * 64, n0 = tn * 64;
+    const int Kper = g.K / g.splitK, kbeg = sk * Kper;
+    const float *Ab0 = g.A0 + (long)b * g.sA, *Ab1 = g.A1 ? g.A1 + (long)b * g.sA : nullptr;
+    const float *Bb0 = g.B0 + (long)b * g.sB, *Bb1 = g.B1 ? g.B1 + (long)b * g.sB : nullptr;
+    double acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0.0;
+    for (int k0 = kbeg; k0 < kbeg + Kper; k0 += BK) {
+        const float *Ap = (k0 < g.ksplitA) ? Ab0 + k0 : Ab1 + (k0 - g.ksplitA);
+        const float *Bp = (k0 < g.ksplitB) ? Bb0 + (long)k0 * g.ldb : Bb1 + (long)(k0 - g.ksplitB) * g.ldb;
+        for (int e = tid; e < 64 * BK; e += 256) {
+            const int r = e / BK, c = e % BK;
+            As[r][c] = Ap[(long)(m0 + r) * g.lda + c];
+        }
+        for (int e = tid; e < BK * 64; e += 256) {
+            const int r = e / 64, c = e % 64;
+            Bs[r][c] = Bp[(long)r * g.ldb + n0 + c];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < BK; ++k) {
+            double a[4], bb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = (double)As[ty + 16 * i][k];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bb[j] = (double)Bs[k][tx + 16 * j];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] += a[i] * bb[j];
+        }
+        __syncthreads();
+    }
+    float *Cb = g.C + (long)b * g.sC + (long)sk * g.sCsplit;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float *c = Cb + (long)(m0 + ty + 16 * i) * g.ldc + n0 + tx + 16 * j;
+            *c = (float)(g.accumulate ? (double)*c + acc[i][j] : acc[i][j]);
+        }
+}
+}  // namespace
+
+int launch_gemm_f64acc(hipStream_t stream, const GemmArgs &g) {
+    if (g.M % 64 || g.N % 64 || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1) return (int)hipErrorInvalidValue;
+    if (g.ksplitA != (1 << 30) && g.ksplitA % BK) return (int)hipErrorInvalidValue;
+    if (g.ksplitB != (1 << 30) && g.ksplitB % BK) return (int)hipErrorInvalidValue;
+    if (g.splitK > 1 && g.accumulate) return (int)hipErrorInvalidValue;
+    dim3 grid((g.M / 64) * (g.N / 64), 1, g.batch * g.splitK);
+    hipLaunchKernelGGL(gemm_f64acc_kernel, grid, dim3(256), 0, stream, g);
+    return (int)hipGetLastError();
+}
+
 int launch_gemm_f32(hipStream_t stream, const GemmArgs &g) {
     if (g.M % 64 || g.N % 64 || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1) return (int)hipErrorInvalidValue;
     if (g.ksplitA != (1 << 30) && g.ksplitA % BK) return (int)hipErrorInvalidValue;

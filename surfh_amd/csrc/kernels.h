@@ -14,7 +14,7 @@ constexpr int SURFH_MAX_TEMPLATES = 8;
 int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, const float *tpl, float *spec,
                        int T, long PL, int LP);
 int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj,
-                       int T, long PL, int LP);
+                       int T, long PL, int LP, bool f64 = false);
 
 // hth[(t,t')][k] = sum_l tpl[t,l] tpl[t',l] |sotf[k][l]|^2   (mixing.py:177-203), full T x T stored
 int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP);
@@ -53,6 +53,8 @@ struct GroupTable {
     const int64_t *dst = nullptr;      // [NG][SCATTER_G]
     const uint32_t *rmw = nullptr;     // [NG][SCATTER_G] read-modify-write chunk masks (as EllTable::rmw)
 };
+// float64-accumulating twin of launch_spmm_rows (every row, read-modify-write where `accumulate`)
+int launch_spmm_rows_f64acc(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate);
 int launch_spmm_group_scatter(hipStream_t s, const GroupTable &t, const float *src, float *dst, int nlam);
 // the gather of launch_spmm_rows_f16 on a grouped table (members = rows neighbouring in cube-location order)
 int launch_spmm_group_gather_f16(hipStream_t s, const GroupTable &t, const float *src, unsigned short *dst16, long plane, int nlam,

@@ -42,14 +42,15 @@ __global__ __launch_bounds__(TPB) void specmix_fwd_kernel(const float *__restric
 constexpr int MAXT = SURFH_MAX_TEMPLATES;
 
 // one workgroup per frequency bin k: madj[t][c][k] = sum_l tpl[t][l] (conj(H) Y)[c][k][l]
+template <typename ACC>
 __global__ __launch_bounds__(TPB) void specmix_adj_kernel(const float *__restrict__ spec,
                                                           const float *__restrict__ sotf,
                                                           const float *__restrict__ tpl, float *__restrict__ madj,
                                                           int T, long PL, int LP) {
     const long k = blockIdx.x;
-    float ar[MAXT], ai[MAXT];
+    ACC ar[MAXT], ai[MAXT];
 #pragma unroll
-    for (int t = 0; t < MAXT; ++t) ar[t] = ai[t] = 0.f;
+    for (int t = 0; t < MAXT; ++t) ar[t] = ai[t] = (ACC)0;
     for (int l4 = threadIdx.x * 4; l4 < LP; l4 += TPB * 4) {
         const float4 hr = *reinterpret_cast<const float4 *>(sotf + k * LP + l4);
         const float4 hi = *reinterpret_cast<const float4 *>(sotf + (PL + k) * LP + l4);
@@ -64,15 +65,15 @@ __global__ __launch_bounds__(TPB) void specmix_adj_kernel(const float *__restric
         for (int t = 0; t < MAXT; ++t)
             if (t < T) {
                 const float4 w = *reinterpret_cast<const float4 *>(tpl + (long)t * LP + l4);
-                ar[t] += w.x * pr.x + w.y * pr.y + w.z * pr.z + w.w * pr.w;
-                ai[t] += w.x * pi.x + w.y * pi.y + w.z * pi.z + w.w * pi.w;
+                ar[t] += (ACC)w.x * (ACC)pr.x + (ACC)w.y * (ACC)pr.y + (ACC)w.z * (ACC)pr.z + (ACC)w.w * (ACC)pr.w;
+                ai[t] += (ACC)w.x * (ACC)pi.x + (ACC)w.y * (ACC)pi.y + (ACC)w.z * (ACC)pi.z + (ACC)w.w * (ACC)pi.w;
             }
     }
-    __shared__ float red[TPB / 64][2 * MAXT];
+    __shared__ ACC red[TPB / 64][2 * MAXT];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) {
-        float a = ar[t], b = ai[t];
+        ACC a = ar[t], b = ai[t];
         for (int o = 32; o > 0; o >>= 1) {
             a += __shfl_down(a, o, 64);
             b += __shfl_down(b, o, 64);
@@ -84,10 +85,10 @@ __global__ __launch_bounds__(TPB) void specmix_adj_kernel(const float *__restric
     }
     __syncthreads();
     if (threadIdx.x < 2 * T) {
-        float s = 0.f;
+        ACC s = (ACC)0;
         for (int w = 0; w < TPB / 64; ++w) s += red[w][threadIdx.x];
         const int t = threadIdx.x >> 1, c = threadIdx.x & 1;
-        madj[((long)t * 2 + c) * PL + k] = s;
+        madj[((long)t * 2 + c) * PL + k] = (float)s;
     }
 }
 
@@ -316,6 +317,21 @@ __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float 
     if (pmax)       // lanes beyond the window carry 0; the whole wave takes part in the reduction
         wave_amax_store(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))), pmax,
                         (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
+}
+
+// verification twin of spmm_rows_kernel: the same rows with float64 accumulation (surfh_config.verify)
+__global__ __launch_bounds__(TPB) void spmm_rows_f64acc_kernel(EllTable t, const float *__restrict__ src, float *__restrict__ dst, int nlam,
+                                                               int accumulate) {
+    const int r = blockIdx.x;
+    const int l = blockIdx.y * TPB + threadIdx.x;
+    if (r >= t.R || l >= nlam) return;
+    const int n = t.cnt[r];
+    const int64_t *col = t.col + (long)r * t.W;
+    const float *val = t.val + (long)r * t.W;
+    double acc = 0.0;
+    for (int e = 0; e < n; ++e) acc += (double)val[e] * (double)src[col[e] + l];
+    float *p = dst + t.dst_off[r] + l;
+    *p = (float)(accumulate ? (double)*p + acc : acc);
 }
 
 // grouped scatter: one workgroup = SCATTER_G neighbouring cube pixels x 1024 wavelengths (see GroupTable)
@@ -848,13 +864,14 @@ int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, cons
 }
 
 int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj, int T,
-                       long PL, int LP) {
+                       long PL, int LP, bool f64) {
     if (T > MAXT) return (int)hipErrorInvalidValue;
     if (T == 0) {
         dim3 grid((LP / 4 + TPB - 1) / TPB, (unsigned)PL);
         hipLaunchKernelGGL(specmix_adj_plane_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP);
     } else {
-        hipLaunchKernelGGL(specmix_adj_kernel, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
+        if (f64) hipLaunchKernelGGL(specmix_adj_kernel<double>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
+        else hipLaunchKernelGGL(specmix_adj_kernel<float>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
     }
     return (int)hipGetLastError();
 }
@@ -926,6 +943,13 @@ int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *
     hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate, pmax);
     if (pmax)
         hipLaunchKernelGGL(rowmax_csr_kernel, dim3((NP + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, pmax, rowptr, idx, NP, rowmax);
+    return (int)hipGetLastError();
+}
+
+int launch_spmm_rows_f64acc(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate) {
+    if (t.R == 0 || nlam <= 0) return 0;
+    dim3 grid((unsigned)t.R, (nlam + TPB - 1) / TPB);
+    hipLaunchKernelGGL(spmm_rows_f64acc_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate);
     return (int)hipGetLastError();
 }
 

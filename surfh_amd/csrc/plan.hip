@@ -155,6 +155,9 @@ struct surfh_plan {
     bool gather_grouped = true;                  // forward gather (fp16 output) likewise
     int wblur_cc = 2;                            // all-consumer 256 x 256 GEMM (gemm_cc16.hip): 0 off, 1 adjoint only, 2 both directions
     bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
+    // surfh_config.verify: every long sum accumulated in float64 (dense DFT products, spectral blur, adjoint spectral mix,
+    // gather / scatter rows) -- the strict dot test; storage stays fp32
+    bool verify = false;
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
@@ -614,6 +617,9 @@ void build_dft(const surfh_plan *p, std::vector<float> &Fi, std::vector<float> &
         }
 }
 
+// fp32-MFMA GEMM, or its float64-accumulating twin in verification mode
+int gemm32(surfh_plan *p, hipStream_t st, const GemmArgs &g) { return p->verify ? launch_gemm_f64acc(st, g) : launch_gemm_f32(st, g); }
+
 // ---- plane-major 2-D transforms (only for the T abundance maps) ---------------------------------
 // real [B][NAP][NBP] -> spec [B][2][KAP][KBP]   (tmp = ycol_maps viewed as [B][NAP][2*KBP])
 int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
@@ -624,7 +630,7 @@ int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     g.M = p->NAP; g.N = 2 * p->KBP; g.K = p->NBP; g.batch = B;
     {
         Prof pr(p, "gemm_dft_rows_fwd_maps");
-        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+        LAUNCH_OK(gemm32(p, p->stream, g));
     }
     GemmArgs h;
     h.A0 = p->Ff; h.lda = 2 * p->NAP; h.sA = 0;
@@ -634,7 +640,7 @@ int rfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     h.M = 2 * p->KAP; h.N = p->KBP; h.K = 2 * p->NAP; h.batch = B;
     {
         Prof pr(p, "gemm_dft_cols_fwd_maps");
-        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+        LAUNCH_OK(gemm32(p, p->stream, h));
     }
     return 0;
 }
@@ -648,7 +654,7 @@ int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     g.M = 2 * p->NAP; g.N = p->KBP; g.K = 2 * p->KAP; g.batch = B;
     {
         Prof pr(p, "gemm_dft_cols_inv_maps");
-        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+        LAUNCH_OK(gemm32(p, p->stream, g));
     }
     GemmArgs h;
     h.A0 = p->ycol_maps; h.A1 = p->ycol_maps + (long)p->NAP * p->KBP; h.ksplitA = p->KBP; h.lda = p->KBP;
@@ -658,7 +664,7 @@ int irfft2_planes(surfh_plan *p, const float *src, float *dst, int B) {
     h.M = p->NAP; h.N = p->NBP; h.K = 2 * p->KBP; h.batch = B;
     {
         Prof pr(p, "gemm_dft_rows_inv_maps");
-        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+        LAUNCH_OK(gemm32(p, p->stream, h));
     }
     return 0;
 }
@@ -674,7 +680,7 @@ int rfft2_lam(surfh_plan *p, const float *src, float *dst) {
     g.M = 2 * p->KBP; g.N = (int)(p->NAP * LP); g.K = p->NBP;
     {
         Prof pr(p, "gemm_dft_rows_fwd");
-        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+        LAUNCH_OK(gemm32(p, p->stream, g));
     }
     GemmArgs h;   // per kb: S[(c,ka)][l] = Ff[(c,ka)][(c',a)] * Z[c'][kb][a][l]
     h.A0 = p->Ff; h.lda = 2 * p->NAP;
@@ -683,7 +689,7 @@ int rfft2_lam(surfh_plan *p, const float *src, float *dst) {
     h.M = 2 * p->KAP; h.N = (int)LP; h.K = 2 * p->NAP; h.batch = p->KBP;
     {
         Prof pr(p, "gemm_dft_cols_fwd");
-        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+        LAUNCH_OK(gemm32(p, p->stream, h));
     }
     return 0;
 }
@@ -698,7 +704,7 @@ int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
     g.M = 2 * p->NAP; g.N = (int)(p->KBP * LP); g.K = 2 * p->KAP;
     {
         Prof pr(p, "gemm_dft_cols_inv");
-        LAUNCH_OK(launch_gemm_f32(p->stream, g));
+        LAUNCH_OK(gemm32(p, p->stream, g));
     }
     GemmArgs h;   // per a: cube[b][a][l] = GiT[b][(c,kb)] * Y[c][a][kb][l]
     h.A0 = p->GiT; h.lda = 2 * p->KBP;
@@ -707,7 +713,7 @@ int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
     h.M = p->NBP; h.N = (int)LP; h.K = 2 * p->KBP; h.batch = p->NAP;
     {
         Prof pr(p, "gemm_dft_rows_inv");
-        LAUNCH_OK(launch_gemm_f32(p->stream, h));
+        LAUNCH_OK(gemm32(p, p->stream, h));
     }
     return 0;
 }
@@ -898,6 +904,8 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
                 LAUNCH_OK(launch_spmm_group_gather_f16(s, c.fwd.g, p->cube, c.Xs16, (long)c.NP * c.K, c.nlam, c.bscale, c.NP, c.K, c.LinP));
             else if (c.Xs16)
                 LAUNCH_OK(launch_spmm_rows_f16(s, c.fwd.t, p->cube, c.Xs16, (long)c.NP * c.K, c.nlam, c.bscale, c.NP, c.K, c.LinP));
+            else if (p->verify)
+                LAUNCH_OK(launch_spmm_rows_f64acc(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0));
             else
                 LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, c.rm_ptr, c.rm_idx,
                                            f16 ? c.amax : nullptr, c.NP));
@@ -916,7 +924,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             Prof pr(p, "gemm_wblur_fwd", sB);
             if (p->wblur_fp32) {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [K][N]
-                LAUNCH_OK(launch_gemm_f32(sB, g));
+                LAUNCH_OK(gemm32(p, sB, g));
             } else {
                 g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
                 g.B3 = c.W3; g.pB3 = (long)c.LdetP * c.K;
@@ -957,7 +965,9 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
                 LAUNCH_OK(launch_cube_to_lam_inner(s, y + c.yoff, c.Xs + c.shift, 0, c.Lin, 1, c.P * c.S * c.aout, 1, c.LinP));
             }
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
-            if (!ref && c.adjT.g.NG)
+            if (p->verify)
+                LAUNCH_OK(launch_spmm_rows_f64acc(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+            else if (!ref && c.adjT.g.NG)
                 LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, p->cube, c.nlam));
             else
                 LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
@@ -977,7 +987,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             Prof pr(p, "gemm_wblur_adj", sB);
             if (p->wblur_fp32) {
                 g.B0 = c.W; g.ldb = c.K;             // B as [K'=l'][N'=k]
-                LAUNCH_OK(launch_gemm_f32(sB, g));
+                LAUNCH_OK(gemm32(p, sB, g));
             } else {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
                 g.B3 = c.Wt3; g.pB3 = (long)c.LdetP * c.K;
@@ -993,7 +1003,9 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
         if (chain(p, sB, s)) return 1;
         {
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
-            if (!ref && c.adjT.g.NG)
+            if (p->verify)
+                LAUNCH_OK(launch_spmm_rows_f64acc(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+            else if (!ref && c.adjT.g.NG)
                 LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, p->cube, c.nlam));
             else
                 LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
@@ -1002,7 +1014,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
     if (rfft2_cube(p, p->cube, p->spec)) return 1;
     {
         Prof pr(p, "specmix_adj");
-        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP));
+        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify));
     }
     if (p->T > 0) {
         if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
@@ -1273,6 +1285,13 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         if (dev_upload(&p->Cma, Cma) || dev_upload(&p->Sma, Sma) || dev_upload(&p->Gc, Gc) || dev_upload(&p->Gs, Gs) ||
             dev_upload(&p->Cf, Cf) || dev_upload(&p->Sf, Sf))
             return bail(1);
+        if (cfg->verify) {      // verification plan: dense DFT products, unfused spectral mix, fp32-operand spectral blur -- all float64-accumulated
+            p->verify = true;
+            p->dense_dft = true;
+            p->fuse_mix = false;
+            p->wblur_fp32 = true;
+            p->overlap = false;
+        }
         const char *e5 = getenv("SURFH_DFT_RX3");
         p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
         if (p->rx3 && !dft_rx3_supported(p->Na, p->Nb, p->NAP, p->KBP, p->LP)) p->rx3 = false;   // row pitch x rows beyond 4 GB
@@ -1329,7 +1348,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         yoff += c.ysize;
         if (c.bsum) continue;
         const bool f16 = p->wblur_pc && !p->wblur_fp32 && p->wblur_f16;
-        c.splitK = pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu, f16 ? 136 : 34,
+        c.splitK = p->verify ? 1 : pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu, f16 ? 136 : 34,
                               (f16 && p->wblur_cc == 2) ? 256 : 128, 256);
         if (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) {
             const long nw = (long)c.LdetP * c.K;

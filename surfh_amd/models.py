@@ -86,9 +86,12 @@ class spectroSigRLSCT(LinOp):
     def __init__(self, sotf, templates, alpha_axis, beta_axis, wavelength_axis, instrs: List[instru.IFU],
                  step_degree: float, pointings: Sequence[instru.CoordList], *, device: int = 0,
                  channels: Optional[Sequence[int]] = None, with_ref: bool = True, stream: Optional[int] = None,
-                 split_k_forward: int = 0, gridding: str = "bilinear", lam_slices=None, channel_opts: Optional[dict] = None):
+                 split_k_forward: int = 0, gridding: str = "bilinear", lam_slices=None, channel_opts: Optional[dict] = None,
+                 verify: bool = False):
         """``sotf=None`` (plane-wise plans only, ``templates=None``) means no spatial blur; ``channel_opts`` are the
-        ``ChannelGeometry`` variants of the slice <-> cube projections (see ``Channel`` below)."""
+        ``ChannelGeometry`` variants of the slice <-> cube projections (see ``Channel`` below).  ``verify=True`` builds the
+        verification plan (include/surfh_amd.h ``surfh_config.verify``): the same operator with every long sum accumulated in
+        float64 -- slow; what the strict dot test with zero-mean test vectors runs on."""
         self.sotf = sotf
         self.alpha_axis = np.asarray(alpha_axis, dtype=np.float64)
         self.beta_axis = np.asarray(beta_axis, dtype=np.float64)
@@ -155,6 +158,7 @@ class spectroSigRLSCT(LinOp):
         cfg.device = device
         cfg.stream = C.c_void_p(stream) if stream else None
         cfg.split_k_forward = split_k_forward
+        cfg.verify = 1 if verify else 0
         plan = C.c_void_p()
         _lib.check(L.surfh_plan_create(C.byref(cfg), C.byref(plan)), ValueError)
         self._L, self._plan = L, plan
