@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3    # MI355X_MICROARCH.md: fp32-input MFMA peak
+MFMA_16BIT_PEAK_TF = 2500.0 # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA peak (the instruction the spectral-blur GEMM issues)
 
 
 def log(*a):
@@ -72,11 +73,12 @@ def cpu_baseline(cfg_name: str, budget_s: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200, help="timed CG iterations (>= 200: the timed region is >= 1 s and holds the residual refreshes of qmm.lcg, one every 50 iterations)")
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="3", choices=["2", "3"])
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
+    ap.add_argument("--no-verify", action="store_true", help="skip the randn dot test on the float64-accumulating verification plan")
     args = ap.parse_args()
 
     import torch
@@ -175,6 +177,27 @@ def main():
                 "note": "|<A^T u, v> - <u, A v>| / |<u, A v>| of the operator this rank holds, at benchmark size; the <=1e-5 "
                         "forward / adjoint gates against the float64 oracle and the bit-exact index tables are tests/ (pytest -m gpu)"}
         log(f"[parity gate] dot-test gap {gate['dot_test_gap']:.2e}")
+        if world == 1 and not args.no_verify:
+            # the reference's own dot test (randn vectors, test/sandbox_dottest.py:16-27) on the verification plan: the same
+            # operator with every long sum accumulated in float64 (surfh_config.verify); gate < 1e-6
+            try:
+                from surfh_amd.models import spectroSigRLSCT
+                t0 = time.time()
+                mv = spectroSigRLSCT(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"], prob["wavel"],
+                                     prob["ifus"], prob["step_deg"], prob["pointings"], device=local, with_ref=False, verify=True)
+                vr, ur = (rng.standard_normal(n).astype(np.float32).astype(np.float64) for n in (mv.isize, mv.osize))
+                lhs = float(np.vdot(np.asarray(mv.rmatvec(ur), dtype=np.float64), vr))
+                rhs = float(np.vdot(ur, np.asarray(mv.matvec(vr), dtype=np.float64)))
+                gate["dot_test_gap_randn_verification_plan"] = abs(lhs - rhs) / abs(rhs)
+                avp = np.asarray(m.matvec(vr), dtype=np.float64)
+                gp = float(np.vdot(np.asarray(m.rmatvec(ur), dtype=np.float64), vr)) - float(np.vdot(ur, avp))
+                gate["dot_test_gap_randn_production_normalised"] = abs(gp) / (np.linalg.norm(ur) * np.linalg.norm(avp))
+                mv.close()
+                log(f"[parity gate] randn dot-test gap on the verification plan {gate['dot_test_gap_randn_verification_plan']:.2e} "
+                    f"({time.time() - t0:.1f}s); production plan, normalised by |u||Av|: {gate['dot_test_gap_randn_production_normalised']:.2e}")
+            except Exception as e:      # the gate must never hide the number
+                gate["dot_test_gap_randn_verification_plan"] = None
+                gate["verification_error"] = repr(e)
 
     if rank == 0:
         for name, (cnt, ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
@@ -225,7 +248,9 @@ def main():
         groups_all = grouped(prof_all)         # warm-up steps: every stage
         roof = None
         stage_ms = {k: round(v[1] / max(n_all, 1), 4) for k, v in sorted(groups_all.items(), key=lambda kv: -kv[1][1])}
-        traffic_file = os.path.join(ROOT, "profiles", f"r01_final_pmc_traffic_config{args.config}.json")
+        traffic_file = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_config{args.config}.json")
+        if not os.path.exists(traffic_file):
+            traffic_file = os.path.join(ROOT, "profiles", f"r01_final_pmc_traffic_config{args.config}.json")
         pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
         if groups:
             dom = max(groups, key=lambda k: groups[k][1])
@@ -238,17 +263,13 @@ def main():
                 flops_step = sum(2.0 * 2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
                                  for c in m.channels)
                 ach = flops_step / per_step / avg_s / 1e12
-                nprod = 3.0 if dom.startswith("gemm_nt_f16x2") else 6.0 if dom.startswith("gemm_nt_bf16x3") else None
-                roof = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": ach / MFMA_F32_PEAK_TF, "traffic": traffic, "kernel": dom, "launches": cnt,
-                        "avg_ms": ms / cnt,
-                        "note": "algorithmic fp32 flops of R/R^T priced against the fp32-input MFMA peak (the dtype the path "
-                                "computes in).  The kernel evaluates each fp32 product as 3 fp16 matrix-core products of a "
-                                "two-piece round-to-nearest operand split (6 bf16 products of a three-piece split with "
-                                "SURFH_WBLUR_F16=0), i.e. it sustains that multiple of this rate on the 16-bit matrix cores"}
-                if nprod:
-                    roof["matrix_core_16bit_tflops"] = nprod * ach
-                    roof["matrix_core_16bit_peak_frac"] = nprod * ach / 2500.0
+                nprod = 3.0 if dom.startswith("gemm_nt_f16x2") else 6.0 if dom.startswith("gemm_nt_bf16x3") else 1.0
+                peak = MFMA_16BIT_PEAK_TF if nprod > 1.0 else MFMA_F32_PEAK_TF
+                roof = {"bound": "mfma", "achieved": nprod * ach, "peak": peak, "unit": "TFLOP/s",
+                        "frac": nprod * ach / peak, "traffic": traffic, "kernel": dom, "launches": cnt,
+                        "avg_ms": ms / cnt, "algorithmic_fp32_tflops": ach,
+                        "note": "matrix-core flops actually issued (each fp32 product = 3 fp16 products of a two-piece split, 6 bf16 "
+                                "products with SURFH_WBLUR_F16=0) against the dense peak of that instruction"}
             else:
                 # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
                 # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel
@@ -263,7 +284,7 @@ def main():
                       else "CG-iterations/sec (forward+adjoint) on 251x251x1024 cube",
             "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32 (storage and accumulation; products as 2-piece fp16 splits in the spectral-blur GEMM and 3-piece bf16 splits in the DFT passes, on the 16-bit matrix cores)", "data": "synthetic",
             "config": {"workload": ("config3: 4 MRS bands 1C,2A,2B,2C, 251x251x4000 cube, 4-point dither, T=4, mu_reg=5e3"
                                     if args.config == "3" else
                                     "config2: band 2A, 251x251x1024 cube, 4-point dither, T=4, mu_reg=5e3"),
@@ -294,11 +315,11 @@ def main():
                              for c in m.channels)
             ach = flops_step * steps_seen / t_s / 1e12
             nprod = 3.0 if gm[0][0].startswith("gemm_nt_f16x2") else 6.0
-            out["roofline_spectral_blur_gemm"] = {"bound": "mfma", "achieved": ach, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                                  "frac": ach / MFMA_F32_PEAK_TF, "kernel": gm[0][0], "launches": n_l,
-                                                  "avg_ms": t_s * 1e3 / n_l,
-                                                  "matrix_core_16bit_tflops": nprod * ach,
-                                                  "matrix_core_16bit_peak_frac": nprod * ach / 2500.0,
+            out["roofline_spectral_blur_gemm"] = {"bound": "mfma", "achieved": nprod * ach, "peak": MFMA_16BIT_PEAK_TF, "unit": "TFLOP/s",
+                                                  "frac": nprod * ach / MFMA_16BIT_PEAK_TF, "kernel": gm[0][0], "launches": n_l,
+                                                  "avg_ms": t_s * 1e3 / n_l, "algorithmic_fp32_tflops": ach,
+                                                  "note": f"matrix-core flops issued ({int(nprod)} 16-bit products per fp32 product) "
+                                                          "against the dense fp16 / bf16 MFMA peak",
                                                   "traffic": pmc.get(gm[0][0], {}).get("hbm_bytes_per_launch")}
         if world == 1 and args.cpu_seconds > 0:
             try:

@@ -193,6 +193,18 @@ int surfh_cg_dir_dev(surfh_plan *plan, float *d_dev, const float *r_dev, int64_t
  * x += s d, r -= s q with s = rr_in / d.q; *rr_out = r.r; d = r + (*rr_out / rr_in) d        */
 int surfh_cg_iter_dev(surfh_plan *plan, float *x_dev, float *r_dev, float *d_dev, const float *q_dev, int64_t n,
                       double rr_in, double *rr_out);
+
+/* The same recurrences with every scalar resident on the device -- NO host synchronisation: r.r of the current iterate lives in
+ * the plan, each call appends the new r.r to a device-side trace.  The multi-GPU loop (surfh_amd/fusion.py) is then
+ * normal operator -> RCCL all-reduce -> one of these calls, all asynchronous on the plan's stream; the host reads the trace
+ * every few iterations for the stopping test (surfh_cg_trace synchronises).                                                 */
+int surfh_cg_begin_dev(surfh_plan *plan, const float *r_dev, int64_t n);                      /* rr = r.r, trace = [rr]        */
+int surfh_cg_iter_nosync_dev(surfh_plan *plan, float *x_dev, float *r_dev, float *d_dev, const float *q_dev, int64_t n);
+/* residual refresh of qmm.lcg, in two halves around the caller's normal operator on x:
+ *   x += (rr / d.q) d          then, with q = Q x:   r = b - q; rr' = r.r; d = r + (rr' / rr) d; rr = rr'                      */
+int surfh_cg_xupdate_nosync_dev(surfh_plan *plan, float *x_dev, const float *d_dev, const float *q_dev, int64_t n);
+int surfh_cg_refresh_nosync_dev(surfh_plan *plan, float *r_dev, const float *b_dev, const float *q_dev, float *d_dev, int64_t n);
+int32_t surfh_cg_trace(surfh_plan *plan, double *out_host, int32_t capacity);                 /* -> number of entries, -1 on error */
 /* r = b - q */
 int surfh_residual_dev(surfh_plan *plan, float *r_dev, const float *b_dev, const float *q_dev, int64_t n);
 

@@ -50,6 +50,7 @@ EXPORTS = [
     "surfh_wct_fwadj", "surfh_wct_expsol", "surfh_tst_create", "surfh_tst_destroy", "surfh_tst_forward",
     "surfh_tst_adjoint", "surfh_tst_fwadj", "surfh_tst_last_error", "surfh_cg", "surfh_cg_cb", "surfh_mmmg", "surfh_cg_planes", "surfh_mmmg_planes", "surfh_maps_to_cube", "surfh_cube_to_maps", "surfh_normal_dev",
     "surfh_prior_add_dev", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_cg_iter_dev", "surfh_residual_dev",
+    "surfh_cg_begin_dev", "surfh_cg_iter_nosync_dev", "surfh_cg_xupdate_nosync_dev", "surfh_cg_refresh_nosync_dev", "surfh_cg_trace",
     "surfh_profile_enable", "surfh_profile_filter", "surfh_profile_count", "surfh_profile_get", "surfh_profile_reset", "surfh_debug_copy",
     "surfh_debug_dims", "surfh_gemm_selftest",
 ]
@@ -102,6 +103,11 @@ def load():
     L.surfh_cg_dir_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_double]
     L.surfh_cg_iter_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_double, c_double_p]
     L.surfh_residual_dev.argtypes = [vp, vp, vp, vp, C.c_int64]
+    L.surfh_cg_begin_dev.argtypes = [vp, vp, C.c_int64]
+    L.surfh_cg_iter_nosync_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int64]
+    L.surfh_cg_xupdate_nosync_dev.argtypes = [vp, vp, vp, vp, C.c_int64]
+    L.surfh_cg_refresh_nosync_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int64]
+    L.surfh_cg_trace.argtypes = [vp, c_double_p, C.c_int32]; L.surfh_cg_trace.restype = C.c_int32
     L.surfh_profile_enable.argtypes = [vp, C.c_int32]
     L.surfh_profile_filter.argtypes = [vp, C.c_char_p]
     L.surfh_profile_count.argtypes = [vp]; L.surfh_profile_count.restype = C.c_int32

@@ -36,6 +36,9 @@ struct EllTable {
     // accumulate mode only, optional: bit j of rmw[r] set = the 1024-wavelength chunk j of row r may already hold another
     // table's contribution and is read-modify-written; clear = the destination is known to be zero, plain store
     const uint32_t *rmw = nullptr;
+    // ... or exactly: wavelengths [rng[r].x, rng[r].y) of row r (relative to the window, multiples of 4) were written earlier in
+    // this pass and are read-modify-written, all others are plain stores -- the destination then needs NO clearing (takes precedence)
+    const int2 *rng = nullptr;
 };
 // pmax ... rowmax (optional, gather mode only): every wave stores max |output| (bit pattern) in its entry of pmax
 // [spmm_rows_waves()]; a second pass takes, for every row of the [NP][K] operand the table writes, the maximum over the
@@ -52,6 +55,7 @@ struct GroupTable {
     const float *val = nullptr;        // [NG][W][SCATTER_G]
     const int64_t *dst = nullptr;      // [NG][SCATTER_G]
     const uint32_t *rmw = nullptr;     // [NG][SCATTER_G] read-modify-write chunk masks (as EllTable::rmw)
+    const int2 *rng = nullptr;         // [NG][SCATTER_G] exact read-modify-write wavelength ranges (as EllTable::rng)
 };
 // float64-accumulating twin of launch_spmm_rows (every row, read-modify-write where `accumulate`)
 int launch_spmm_rows_f64acc(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate);

@@ -308,7 +308,10 @@ __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float 
             acc.x += v0 * x0.x; acc.y += v0 * x0.y; acc.z += v0 * x0.z; acc.w += v0 * x0.w;
         }
         float4 *p = reinterpret_cast<float4 *>(dst + t.dst_off[r] + l4);
-        if (accumulate && (!t.rmw || ((t.rmw[r] >> blockIdx.y) & 1u))) {      // workgroup-uniform
+        bool rm = accumulate != 0;
+        if (rm && t.rng) { const int2 g2 = t.rng[r]; rm = l4 >= g2.x && l4 < g2.y; }
+        else if (rm && t.rmw) rm = ((t.rmw[r] >> blockIdx.y) & 1u) != 0;      // workgroup-uniform
+        if (rm) {
             const float4 o = *p;
             acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
         }
@@ -372,7 +375,10 @@ __global__ __launch_bounds__(TPB) void spmm_group_scatter_kernel(GroupTable t, c
         if (d < 0) continue;                               // workgroup-uniform
         float4 *p = reinterpret_cast<float4 *>(dst + d + l4);
         float4 a = acc[g];
-        if ((t.rmw[(long)gi * SCATTER_G + g] >> blockIdx.y) & 1u) {
+        bool rm;
+        if (t.rng) { const int2 g2 = t.rng[(long)gi * SCATTER_G + g]; rm = l4 >= g2.x && l4 < g2.y; }
+        else rm = ((t.rmw[(long)gi * SCATTER_G + g] >> blockIdx.y) & 1u) != 0;
+        if (rm) {
             const float4 o = *p;
             a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
         }

@@ -75,6 +75,7 @@ struct DevEll {
     int64_t *col = nullptr, *dst = nullptr;
     float *val = nullptr;
     uint32_t *rmw = nullptr;            // scatter tables: chunks of a row that need read-modify-write (EllTable::rmw)
+    int2 *rng = nullptr, *g_rng = nullptr;   // ... or the exact wavelength ranges (EllTable::rng, GroupTable::rng)
     std::vector<int64_t> host_dst;      // kept for the scatter tables until the plan is complete
     // the same table with its rows grouped SCATTER_G at a time (GroupTable)
     GroupTable g;
@@ -161,11 +162,17 @@ struct surfh_plan {
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
+    // accumulator of the exact adjoint: cleared ONCE at plan creation.  Every scatter row knows which of its wavelengths an
+    // earlier channel has already written in the same pass (read-modify-write) and stores the others, so nothing stale
+    // survives a pass and no per-call clear is needed (nullptr: the tables could not express that -- clear `cube` every call)
+    float *gcube = nullptr;
     std::vector<Channel> ch;
     long isize = 0, osize = 0;
     // CG
     float *cg_x = nullptr, *cg_r = nullptr, *cg_d = nullptr, *cg_q = nullptr, *cg_b = nullptr, *cg_y = nullptr, *cg_qm = nullptr, *cg_dd = nullptr;
     double *dscal = nullptr, *dscratch = nullptr;   // [8] device scalars, [1024] partial sums
+    double *cg_hist = nullptr;                     // device-resident r.r trace of the no-host-sync CG blocks (CG_HIST_CAP entries)
+    int cg_hist_n = 0;
     // profiling
     bool prof = false;
     std::string prof_filter;                     // non-empty: only stages whose name starts with it are bracketed by events
@@ -282,6 +289,8 @@ void free_ell(DevEll *d) {
     hipFree(d->g_val);
     hipFree(d->g_rmw);
     hipFree(d->rmw);
+    hipFree(d->rng);
+    hipFree(d->g_rng);
     hipFree(d->cnt);
     hipFree(d->col);
     hipFree(d->val);
@@ -289,11 +298,13 @@ void free_ell(DevEll *d) {
 }
 
 // rows [r, r + n) of h taken as one group: union of their taps with one weight per member
-int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>> &runs, const std::vector<uint32_t> *mask, DevEll *d) {
+int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>> &runs, const std::vector<uint32_t> *mask, DevEll *d,
+                  const std::vector<int2> *ranges = nullptr) {
     const size_t NG = runs.size();
     std::vector<std::vector<std::pair<int64_t, std::array<float, SCATTER_G>>>> grows(NG);
     std::vector<int64_t> gdst(NG * SCATTER_G, -1);
     std::vector<uint32_t> grmw(NG * SCATTER_G, 0u);
+    std::vector<int2> grng(ranges ? NG * SCATTER_G : 0, make_int2(0, 0));
     int W = 1;
     for (size_t gi = 0; gi < NG; ++gi) {
         const size_t r = runs[gi].first, n = runs[gi].second;
@@ -306,6 +317,7 @@ int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>>
             }
             gdst[gi * SCATTER_G + m] = h.dst[r + m];
             if (mask) grmw[gi * SCATTER_G + m] = (*mask)[r + m];
+            if (ranges) grng[gi * SCATTER_G + m] = (*ranges)[r + m];
         }
         grows[gi].assign(u.begin(), u.end());
         W = std::max(W, (int)grows[gi].size());
@@ -324,6 +336,10 @@ int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>>
         dev_upload(&d->g_rmw, grmw))
         return 1;
     d->g.NG = (int)NG; d->g.W = W; d->g.cnt = d->g_cnt; d->g.col = d->g_col; d->g.val = d->g_val; d->g.dst = d->g_dst; d->g.rmw = d->g_rmw;
+    if (ranges) {
+        if (dev_upload(&d->g_rng, grng)) return 1;
+        d->g.rng = d->g_rng;
+    }
     return 0;
 }
 
@@ -953,7 +969,10 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
     // overlaps scatter(c); the scatters stay in channel order on one stream because their windows overlap
     hipStream_t sB = (p->overlap && p->stream2) ? p->stream2 : s;
     if (chain(p, s, sB)) return 1;     // y (and the previous users of Xs / ymat) are ordered before the second stream's work
-    {
+    // the exact adjoint accumulates in its own buffer without clearing it (surfh_plan::gcube); the reference adjoint and the
+    // verification plan read-modify-write every row of the cleared work cube
+    float *const acc = (!ref && p->gcube) ? p->gcube : p->cube;
+    if (acc == p->cube) {
         Prof pr(p, "fill_zero");
         LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
     }
@@ -966,11 +985,11 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             }
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
             if (p->verify)
-                LAUNCH_OK(launch_spmm_rows_f64acc(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+                LAUNCH_OK(launch_spmm_rows_f64acc(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, acc, c.nlam, 1));
             else if (!ref && c.adjT.g.NG)
-                LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, p->cube, c.nlam));
+                LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, acc, c.nlam));
             else
-                LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+                LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, acc, c.nlam, 1));
             continue;
         }
         const bool f16 = c.W16 != nullptr;
@@ -1004,14 +1023,14 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
         {
             Prof pr(p, ref ? "spmm_degrid_ref" : "spmm_scatter_adj");
             if (p->verify)
-                LAUNCH_OK(launch_spmm_rows_f64acc(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+                LAUNCH_OK(launch_spmm_rows_f64acc(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, acc, c.nlam, 1));
             else if (!ref && c.adjT.g.NG)
-                LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, p->cube, c.nlam));
+                LAUNCH_OK(launch_spmm_group_scatter(s, c.adjT.g, c.Xs, acc, c.nlam));
             else
-                LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, p->cube, c.nlam, 1));
+                LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, acc, c.nlam, 1));
         }
     }
-    if (rfft2_cube(p, p->cube, p->spec)) return 1;
+    if (rfft2_cube(p, acc, p->spec)) return 1;
     {
         Prof pr(p, "specmix_adj");
         LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify));
@@ -1084,11 +1103,12 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipSetDevice(p->dev);
     if (p->stream) hipStreamSynchronize(p->stream);
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
-                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
+                     p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->gcube, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
         hipFree(v);
     hipFree(p->dft3);
     hipFree(p->dscal);
     hipFree(p->dscratch);
+    hipFree(p->cg_hist);
     for (auto &c : p->ch) {
         for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
         hipFree(c.W3);
@@ -1399,6 +1419,11 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         // chunk; everywhere else the destination is still zero and the kernel stores without reading (the windows of
         // adjacent bands overlap by a tenth, so most of the traffic is of the second kind).
         const long npixrows = (long)p->NBP * p->NAP;
+        bool exact_ok = !p->verify;
+        {
+            const char *ec = getenv("SURFH_ADJ_CLEAR");
+            if (ec && ec[0] == '1') exact_ok = false;      // A/B: clear the accumulator every call, chunk masks
+        }
         std::vector<std::vector<uint8_t>> touched(p->ch.size());
         for (size_t ci = 0; ci < p->ch.size(); ++ci) {
             Channel &c = p->ch[ci];
@@ -1406,10 +1431,25 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             touched[ci].assign((size_t)npixrows, 0);
             const int nchunk = (c.nlam / 4 + 255) / 256;
             std::vector<uint32_t> mask(dst.size(), nchunk > 32 ? 0xFFFFFFFFu : 0u);
+            std::vector<int2> ranges(dst.size(), make_int2(0, 0));
             for (size_t r = 0; r < dst.size(); ++r) {
                 const long pix = (dst[r] - c.ws0a) / p->LP;
                 if (pix < 0 || pix >= npixrows) return bail(fail("scatter table: bad destination"));
                 touched[ci][pix] = 1;
+                {   // exact form: union of the earlier channels' windows at this pixel, inside this channel's window
+                    int lo = INT32_MAX, hi = INT32_MIN, covered = 0;
+                    for (size_t cj = 0; cj < ci; ++cj) {
+                        if (!touched[cj][pix]) continue;
+                        const Channel &o = p->ch[cj];
+                        const int a = std::max(o.ws0a, c.ws0a), b = std::min(o.ws0a + o.nlam, c.ws0a + c.nlam);
+                        if (a >= b) continue;
+                        if (covered && (a > hi || b < lo)) exact_ok = false;      // two separate pieces: not one range
+                        lo = std::min(lo, a);
+                        hi = std::max(hi, b);
+                        covered = 1;
+                    }
+                    if (covered) ranges[r] = make_int2(lo - c.ws0a, hi - c.ws0a);
+                }
                 if (nchunk > 32) continue;
                 for (size_t cj = 0; cj < ci; ++cj) {
                     if (!touched[cj][pix]) continue;
@@ -1434,14 +1474,25 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                     runs.push_back({r, n});
                     r += n;
                 }
-                if (upload_groups(h, runs, &mask, &c.adjT)) return bail(1);
+                if (upload_groups(h, runs, &mask, &c.adjT, &ranges)) return bail(1);
             }
             c.adjT_host = HostEll();
-            if (dev_upload(&c.adjT.rmw, mask)) return bail(1);
+            if (dev_upload(&c.adjT.rmw, mask) || dev_upload(&c.adjT.rng, ranges)) return bail(1);
+            c.adjT.t.rng = c.adjT.rng;
             const char *ea = getenv("SURFH_SCATTER_RMW_ALL");
             if (!(ea && ea[0] == '1')) c.adjT.t.rmw = c.adjT.rmw;        // 1: read-modify-write everywhere (A/B)
             c.adjT.host_dst.clear();
             c.adjT.host_dst.shrink_to_fit();
+        }
+        if (exact_ok && !p->ch.empty()) {      // dedicated accumulator, cleared once: the exact ranges keep it consistent
+            const size_t ncube = (size_t)p->NBP * p->NAP * p->LP;
+            if (dev_alloc(&p->gcube, ncube)) return bail(1);
+            if (hipMemset(p->gcube, 0, ncube * sizeof(float)) != hipSuccess) return bail(fail("memset failed"));
+        } else {
+            for (auto &c : p->ch) {
+                c.adjT.t.rng = nullptr;
+                c.adjT.g.rng = nullptr;
+            }
         }
     }
     if (dev_alloc(&p->io_x, (size_t)p->isize) || dev_alloc(&p->io_y, (size_t)p->osize) || dev_alloc(&p->cg_y, (size_t)p->osize) ||
@@ -1660,6 +1711,60 @@ int surfh_cg_iter_dev(surfh_plan *p, float *x, float *r, float *d, const float *
     HIP_OK(hipMemcpyAsync(rr_out, p->dscal + 2, sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));   // also covers the pageable rr_in copy
     return 0;
+}
+// ---- the same blocks with every scalar kept on the device: nothing here synchronises with the host.  dscal[0] = r.r of the
+// current iterate, the trace goes to cg_hist (read back with surfh_cg_trace).  For the multi-GPU loop: the only other work of an
+// iteration is the normal operator and the all-reduce, both asynchronous on the plan's stream.
+static constexpr int CG_HIST_CAP = 1 << 16;
+static int cg_hist_push(surfh_plan *p, const double *src) {
+    if (!p->cg_hist && dev_alloc(&p->cg_hist, (size_t)CG_HIST_CAP)) return 1;
+    if (p->cg_hist_n >= CG_HIST_CAP) return fail("CG trace full (%d iterations): read it with surfh_cg_trace", CG_HIST_CAP);
+    HIP_OK(hipMemcpyAsync(p->cg_hist + p->cg_hist_n, src, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    ++p->cg_hist_n;
+    return 0;
+}
+int surfh_cg_begin_dev(surfh_plan *p, const float *r, int64_t n) {         /* rr = r.r; trace restarts with it */
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    p->cg_hist_n = 0;
+    LAUNCH_OK(launch_dot(p->stream, r, r, n, p->dscratch, p->dscal + 0));
+    return cg_hist_push(p, p->dscal + 0);
+}
+int surfh_cg_iter_nosync_dev(surfh_plan *p, float *x, float *r, float *d, const float *q, int64_t n) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    LAUNCH_OK(launch_dot(p->stream, d, q, n, p->dscratch, p->dscal + 1));
+    LAUNCH_OK(launch_cg_step(p->stream, x, r, d, q, n, p->dscal + 0, p->dscal + 1, p->dscratch, p->dscal + 2));
+    LAUNCH_OK(launch_cg_dir(p->stream, d, r, n, p->dscal + 2, p->dscal + 0));
+    HIP_OK(hipMemcpyAsync(p->dscal + 0, p->dscal + 2, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    return cg_hist_push(p, p->dscal + 2);
+}
+/* the residual-refresh iteration of qmm.lcg in two halves around the caller's normal operator on x:
+ * x += (rr / d.q) d   ...   r = b - q; rr' = r.r; d = r + (rr' / rr) d; rr = rr'                                   */
+int surfh_cg_xupdate_nosync_dev(surfh_plan *p, float *x, const float *d, const float *q, int64_t n) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    LAUNCH_OK(launch_dot(p->stream, d, q, n, p->dscratch, p->dscal + 1));
+    LAUNCH_OK(launch_cg_xupdate(p->stream, x, d, n, p->dscal + 0, p->dscal + 1));
+    return 0;
+}
+int surfh_cg_refresh_nosync_dev(surfh_plan *p, float *r, const float *b, const float *q, float *d, int64_t n) {
+    if (!p) return fail("null plan");
+    HIP_OK(hipSetDevice(p->dev));
+    LAUNCH_OK(launch_residual(p->stream, r, b, q, n));
+    LAUNCH_OK(launch_dot(p->stream, r, r, n, p->dscratch, p->dscal + 2));
+    LAUNCH_OK(launch_cg_dir(p->stream, d, r, n, p->dscal + 2, p->dscal + 0));
+    HIP_OK(hipMemcpyAsync(p->dscal + 0, p->dscal + 2, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
+    return cg_hist_push(p, p->dscal + 2);
+}
+/* synchronises the plan's stream and copies the r.r trace (entry 0 = surfh_cg_begin_dev); returns the number of entries */
+int32_t surfh_cg_trace(surfh_plan *p, double *out, int32_t cap) {
+    if (!p || !out) return -1;
+    if (hipSetDevice(p->dev) != hipSuccess) return -1;
+    const int n = p->cg_hist_n < cap ? p->cg_hist_n : cap;
+    if (hipStreamSynchronize(p->stream) != hipSuccess) return -1;
+    if (n > 0 && hipMemcpy(out, p->cg_hist, (size_t)n * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    return n;
 }
 int surfh_residual_dev(surfh_plan *p, float *r, const float *b, const float *q, int64_t n) {
     if (!p) return fail("null plan");
@@ -2030,8 +2135,8 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
     std::string w(which ? which : "");
     dims[0] = dims[1] = dims[2] = dims[3] = 1;
     *ptr = nullptr;
-    if (w == "blurred" || w == "gcube") {          // [beta][alpha][lambda]
-        *ptr = p->cube; dims[0] = p->NBP; dims[1] = p->NAP; dims[2] = p->LP;
+    if (w == "blurred" || w == "gcube") {          // [beta][alpha][lambda]; the exact adjoint's accumulator may be its own buffer
+        *ptr = (w == "gcube" && p->gcube) ? p->gcube : p->cube; dims[0] = p->NBP; dims[1] = p->NAP; dims[2] = p->LP;
     } else if (w == "spec") {                       // [2][k_alpha][k_beta][lambda]
         *ptr = p->spec; dims[0] = 2; dims[1] = p->KAP; dims[2] = p->KBP; dims[3] = p->LP;
     } else if (w == "mhat" && p->T > 0) {

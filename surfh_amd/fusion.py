@@ -327,6 +327,7 @@ class DistributedFusion:
     def start(self, y, mu=1.0, mu_reg=0.0, x0=None):
         torch, m = self.torch, self.model
         dev = self.dev
+        self._nosync = hasattr(m, "cg_iter_nosync_dev")          # the HIP operator keeps the CG scalars on the device
         with self._ctx():
             shape = m.ishape
             self.x = torch.zeros(shape, dtype=torch.float32, device=dev) if x0 is None else \
@@ -340,37 +341,56 @@ class DistributedFusion:
             self.normal(self.x, self.q, mu, mu_reg)
             self.r = self.b - self.q
             self.d = self.r.clone()
-            self.rr = m.dot_dev(self.r, self.r, self.n)
+            if self._nosync:
+                m.cg_begin_dev(self.r, self.n)
+                self._trace = None
+            else:
+                self.rr = m.dot_dev(self.r, self.r, self.n)
+                self._trace = [self.rr]
         self.mu, self.mu_reg = mu, mu_reg
-        self.grad_norm = [self.rr]
         self.it = 0
 
+    @property
+    def grad_norm(self):
+        """r.r of every iterate so far (reading it synchronises the device when the scalars live there)."""
+        return list(self.model.cg_trace()) if self._nosync else list(self._trace)
+
     def step(self, refresh=50):
-        """One CG iteration (qmm.lcg loop body; oracle/surfh_oracle.py:lcg documents the recurrences)."""
+        """One CG iteration (qmm.lcg loop body; oracle/surfh_oracle.py:lcg documents the recurrences).  With the HIP operator
+        nothing here waits for the device: normal operator, all-reduce and vector updates are queued on the plan's stream and
+        the step lengths are formed on the device from device-resident scalars."""
         torch, m = self.torch, self.model
+        fresh = bool(refresh) and self.it % refresh == 0
         with self._ctx():
             self.normal(self.d, self.q, self.mu, self.mu_reg)
-            fused = getattr(m, "cg_iter_dev", None)
-            if fused is not None and not (refresh and self.it % refresh == 0):
-                rr_new = fused(self.x, self.r, self.d, self.q, self.n, self.rr)     # one host sync per iteration
+            if self._nosync:
+                if fresh:           # residual recomputed from scratch
+                    m.cg_xupdate_nosync_dev(self.x, self.d, self.q, self.n)
+                    self.normal(self.x, self.q, self.mu, self.mu_reg)
+                    m.cg_refresh_nosync_dev(self.r, self.b, self.q, self.d, self.n)
+                else:
+                    m.cg_iter_nosync_dev(self.x, self.r, self.d, self.q, self.n)
             else:
                 rr_new = m.cg_step_dev(self.x, self.r, self.d, self.q, self.n, self.rr)
-                if refresh and self.it % refresh == 0:
+                if fresh:
                     self.normal(self.x, self.q, self.mu, self.mu_reg)
                     m.residual_dev(self.r, self.b, self.q, self.n)
                     rr_new = m.dot_dev(self.r, self.r, self.n)
                 m.cg_dir_dev(self.d, self.r, self.n, rr_new / self.rr)
-        self.rr = rr_new
-        self.grad_norm.append(rr_new)
+                self.rr = rr_new
+                self._trace.append(rr_new)
         self.it += 1
-        return rr_new
 
-    def lcg(self, y, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+    def lcg(self, y, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, check_every=8):
+        """``check_every``: with device-resident scalars the stopping test reads the trace only every that many iterations
+        (the iterates stop at the first multiple of it past the tolerance; ``check_every=1`` reproduces qmm.lcg's count)."""
         self.start(y, mu, mu_reg, x0)
-        for _ in range(max_iter):
-            rr = self.step(refresh)
-            if np.sqrt(rr) < self.n * tol:
-                break
+        for i in range(max_iter):
+            self.step(refresh)
+            if not self._nosync or (i + 1) % check_every == 0 or i + 1 == max_iter:
+                if np.sqrt(self.grad_norm[-1]) < self.n * tol:
+                    break
         self._sync()
-        return OptimizeResult(x=self.x.cpu().numpy().astype(np.float64), grad_norm=list(self.grad_norm), nit=self.it,
-                              success=bool(np.sqrt(self.rr) < self.n * tol))
+        gn = self.grad_norm
+        return OptimizeResult(x=self.x.cpu().numpy().astype(np.float64), grad_norm=gn, nit=self.it,
+                              success=bool(np.sqrt(gn[-1]) < self.n * tol))

@@ -249,6 +249,27 @@ class spectroSigRLSCT(LinOp):
     def cg_dir_dev(self, d_t, r_t, n: int, beta: float):
         _lib.check(self._L.surfh_cg_dir_dev(self._plan, _ptr(d_t), _ptr(r_t), int(n), float(beta)))
 
+    # device-resident CG scalars: nothing below synchronises with the host (include/surfh_amd.h)
+    def cg_begin_dev(self, r_t, n: int):
+        _lib.check(self._L.surfh_cg_begin_dev(self._plan, _ptr(r_t), int(n)))
+
+    def cg_iter_nosync_dev(self, x_t, r_t, d_t, q_t, n: int):
+        _lib.check(self._L.surfh_cg_iter_nosync_dev(self._plan, _ptr(x_t), _ptr(r_t), _ptr(d_t), _ptr(q_t), int(n)))
+
+    def cg_xupdate_nosync_dev(self, x_t, d_t, q_t, n: int):
+        _lib.check(self._L.surfh_cg_xupdate_nosync_dev(self._plan, _ptr(x_t), _ptr(d_t), _ptr(q_t), int(n)))
+
+    def cg_refresh_nosync_dev(self, r_t, b_t, q_t, d_t, n: int):
+        _lib.check(self._L.surfh_cg_refresh_nosync_dev(self._plan, _ptr(r_t), _ptr(b_t), _ptr(q_t), _ptr(d_t), int(n)))
+
+    def cg_trace(self, cap: int = 1 << 16) -> np.ndarray:
+        """r.r of every iterate since ``cg_begin_dev`` (synchronises the plan's stream)."""
+        out = np.zeros(cap, dtype=np.float64)
+        n = self._L.surfh_cg_trace(self._plan, _lib.dptr(out), int(cap))
+        if n < 0:
+            raise RuntimeError("surfh_cg_trace failed")
+        return out[:n].copy()
+
     def residual_dev(self, r_t, b_t, q_t, n: int):
         _lib.check(self._L.surfh_residual_dev(self._plan, _ptr(r_t), _ptr(b_t), _ptr(q_t), int(n)))
 

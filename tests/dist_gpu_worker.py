@@ -1,0 +1,38 @@
+"""One rank of the multi-process rehearsal of ``DistributedFusion`` with the REAL HIP operator on a one-GPU box:
+every rank on device 0, collectives over gloo (RCCL refuses two ranks on one device; production is nccl, one rank per GPU)."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import dist_worker as dw  # noqa: E402
+from surfh_amd.fusion import DistributedFusion  # noqa: E402
+
+
+def main():
+    rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prob = dw.small_problem()
+    fus = DistributedFusion(prob, rank=rank, world=world, device=0, split=os.environ.get("DIST_SPLIT", "lambda"))
+    y = fus.make_data(prob["maps"], noise_rel=0.0)
+    res = fus.lcg(y, mu=1.0, mu_reg=50.0, max_iter=int(os.environ.get("DIST_ITERS", "6")), tol=1e-14,
+                  refresh=int(os.environ.get("DIST_REFRESH", "50")))
+    xs = [torch.zeros_like(fus.x) for _ in range(world)]
+    dist.all_gather(xs, fus.x)
+    same = all(torch.equal(xs[0], t) for t in xs)
+    if rank == 0:
+        np.savez(os.environ["DIST_OUT"], x=res.x, grad_norm=np.array(res.grad_norm), same=same,
+                 n_groups=len(fus.unit_groups), assignment=np.array(repr(fus.assignment)), nosync=bool(fus._nosync))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

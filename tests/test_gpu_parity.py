@@ -492,3 +492,27 @@ def test_alternative_kernel_paths(env):
         assert ey < TOL and ea < TOL
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("maker", [problems.config1, problems.two_channel_small, problems.two_channel_disjoint],
+                         ids=["config1", "overlapping_windows", "disjoint_windows"])
+def test_adjoint_accumulator_carries_no_state(maker):
+    """The exact adjoint accumulates in a cube that is cleared once, at plan creation: every scatter row stores where no earlier
+    channel of the same pass has written and read-modify-writes exactly the wavelengths one has.  Whatever ran before -- other
+    data, the reference adjoint, a forward -- the result of a call is bit-identical, and zero data give exactly zero."""
+    cfg = maker()
+    om = problems.oracle_model(cfg, box="direct")
+    m = build_model(cfg)
+    try:
+        rng = np.random.default_rng(21)
+        u1, u2 = rng.standard_normal(m.osize), 1e3 * rng.standard_normal(m.osize)
+        a1 = m.adjoint(u1)
+        assert rel(a1, om.adjoint(u1)) < TOL
+        m.adjoint(u2)
+        m.adjoint_ref(u2)
+        m.forward(cfg["maps"])
+        assert np.array_equal(m.adjoint(u1), a1)
+        assert np.all(m.adjoint(np.zeros(m.osize)) == 0)
+        assert rel(m.adjoint(u2), om.adjoint(u2)) < TOL
+    finally:
+        m.close()
