@@ -179,10 +179,23 @@ int surfh_cg_planes(surfh_plan *plan, const float *y, double mu, double mu_reg, 
 int surfh_mmmg_planes(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,
                       double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
 
+/* the two plane-wise solvers with qmm's per-iteration callback (criterion_2D.py:163-225): grad_norm is the trace so far,
+ * [it + 1][Lc] values, x the current iterate [Lc][Na][Nb] on the host; a non-zero return stops the loop */
+int surfh_cg_planes_cb(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,
+                       double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit,
+                       surfh_cg_callback callback, void *user);
+int surfh_mmmg_planes_cb(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,
+                         double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit,
+                         surfh_cg_callback callback, void *user);
+
 /* CG building blocks on device vectors, for the multi-GPU driver (one plan per rank,
  * RCCL all-reduce of `q` between surfh_normal_dev and surfh_cg_step_dev).            */
 int surfh_normal_dev(surfh_plan *plan, const float *d_dev, float *q_dev, double mu);          /* q  = mu A^T A d   */
 int surfh_prior_add_dev(surfh_plan *plan, const float *d_dev, float *q_dev, double mu_reg);   /* q += mu_reg L d   */
+/* which quadratic regulariser L the solvers and surfh_prior_add_dev apply (QuadCriterion_MRS's `gradient`, fusion_CT.py:98-106,141-162):
+ * 0 = "separated": Dr^T Dr + Dc^T Dc, circular first differences NpDiff_r / NpDiff_c (fusion_CT.py:16-43) -- the default;
+ * 1 = "joint": D^T D with D the circular convolution by the 3 x 3 Laplacian (Difference_Operator_Joint, fusion_CT.py:45-62).  */
+int surfh_set_prior(surfh_plan *plan, int32_t kind);
 int surfh_dot_dev(surfh_plan *plan, const float *a_dev, const float *b_dev, int64_t n, double *out_host);
 /* x += s d ; r -= s q ; returns r.r  (s = rr / d.q computed on device from rr_in)    */
 int surfh_cg_step_dev(surfh_plan *plan, float *x_dev, float *r_dev, const float *d_dev,

@@ -48,8 +48,8 @@ EXPORTS = [
     "surfh_stream", "surfh_forward", "surfh_adjoint", "surfh_adjoint_ref", "surfh_fwadj", "surfh_forward_dev",
     "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev", "surfh_wct_forward", "surfh_wct_adjoint",
     "surfh_wct_fwadj", "surfh_wct_expsol", "surfh_tst_create", "surfh_tst_destroy", "surfh_tst_forward",
-    "surfh_tst_adjoint", "surfh_tst_fwadj", "surfh_tst_last_error", "surfh_cg", "surfh_cg_cb", "surfh_mmmg", "surfh_cg_planes", "surfh_mmmg_planes", "surfh_maps_to_cube", "surfh_cube_to_maps", "surfh_normal_dev",
-    "surfh_prior_add_dev", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_cg_iter_dev", "surfh_residual_dev",
+    "surfh_tst_adjoint", "surfh_tst_fwadj", "surfh_tst_last_error", "surfh_cg", "surfh_cg_cb", "surfh_mmmg", "surfh_cg_planes", "surfh_mmmg_planes", "surfh_cg_planes_cb", "surfh_mmmg_planes_cb", "surfh_maps_to_cube", "surfh_cube_to_maps", "surfh_normal_dev",
+    "surfh_prior_add_dev", "surfh_set_prior", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_cg_iter_dev", "surfh_residual_dev",
     "surfh_cg_begin_dev", "surfh_cg_iter_nosync_dev", "surfh_cg_xupdate_nosync_dev", "surfh_cg_refresh_nosync_dev", "surfh_cg_trace",
     "surfh_profile_enable", "surfh_profile_filter", "surfh_profile_count", "surfh_profile_get", "surfh_profile_reset", "surfh_debug_copy",
     "surfh_debug_dims", "surfh_gemm_selftest",
@@ -94,10 +94,13 @@ def load():
                               c_float_p, c_double_p, c_int32_p, CG_CALLBACK, vp]
     L.surfh_mmmg.argtypes = L.surfh_cg_cb.argtypes
     L.surfh_mmmg_planes.argtypes = L.surfh_cg_planes.argtypes
+    L.surfh_cg_planes_cb.argtypes = L.surfh_cg_cb.argtypes
+    L.surfh_mmmg_planes_cb.argtypes = L.surfh_cg_cb.argtypes
     L.surfh_maps_to_cube.argtypes = [vp, c_double_p, C.c_int32, C.c_int32, c_float_p, c_float_p]
     L.surfh_cube_to_maps.argtypes = [vp, c_double_p, C.c_int32, C.c_int32, c_float_p, c_float_p]
     L.surfh_normal_dev.argtypes = [vp, vp, vp, C.c_double]
     L.surfh_prior_add_dev.argtypes = [vp, vp, vp, C.c_double]
+    L.surfh_set_prior.argtypes = [vp, C.c_int32]
     L.surfh_dot_dev.argtypes = [vp, vp, vp, C.c_int64, c_double_p]
     L.surfh_cg_step_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_double, c_double_p]
     L.surfh_cg_dir_dev.argtypes = [vp, vp, vp, C.c_int64, C.c_double]

@@ -96,6 +96,8 @@ int launch_fill_zero(hipStream_t s, float *p, long n);
 // ---- CG vector kernels (qmm.lcg loop body; fusion_CT.py:16-43 priors) --------------------------
 // q += mu_reg * (Dr^T Dr + Dc^T Dc) d   on [T][na][nb], circular
 int launch_prior_add(hipStream_t s, const float *d, float *q, int T, int na, int nb, float mu_reg);
+// q += mu_reg * L^T L d, L = circular 3 x 3 Laplacian (the reference's joint prior, fusion_CT.py:45-62)
+int launch_prior_joint_add(hipStream_t s, const float *d, float *q, int T, int na, int nb, float mu_reg);
 int launch_scale(hipStream_t s, float *x, long n, float a);
 // out[0] = sum a*b (fp64 accumulation); scratch holds >= 1024 doubles
 int launch_dot(hipStream_t s, const float *a, const float *b, long n, double *scratch, double *out);

@@ -631,6 +631,24 @@ __global__ __launch_bounds__(TPB) void prior_add_kernel(const float *__restrict_
     q[t * na * nb + (long)i * nb + j] += mu * lap;
 }
 
+// joint prior: q += mu * L^T L d with L the circular convolution by udft's 3 x 3 Laplacian [[0,-1,0],[-1,4,-1],[0,-1,0]]
+// centred on the pixel (Difference_Operator_Joint.DtD, fusion_CT.py:45-62: |ir2fr(laplacian(2))|^2 in the Fourier domain).
+// L is symmetric, L^T L is the 13-tap stencil 20 / -8 (axis neighbours) / 2 (diagonals) / 1 (axis distance 2).
+__global__ __launch_bounds__(TPB) void prior_joint_add_kernel(const float *__restrict__ d, float *__restrict__ q, int na, int nb, float mu) {
+    const int j = blockIdx.x * TPB + threadIdx.x;
+    const int i = blockIdx.y;
+    const long t = blockIdx.z;
+    if (j >= nb) return;
+    const float *p = d + t * na * nb;
+    auto wi = [&](int v) { return ((v % na) + na) % na; };
+    auto wj = [&](int v) { return ((v % nb) + nb) % nb; };
+    auto at = [&](int a, int b) { return p[(long)wi(a) * nb + wj(b)]; };
+    const float v = 20.f * at(i, j) - 8.f * (at(i - 1, j) + at(i + 1, j) + at(i, j - 1) + at(i, j + 1)) +
+                    2.f * (at(i - 1, j - 1) + at(i - 1, j + 1) + at(i + 1, j - 1) + at(i + 1, j + 1)) +
+                    (at(i - 2, j) + at(i + 2, j) + at(i, j - 2) + at(i, j + 2));
+    q[t * na * nb + (long)i * nb + j] += mu * v;
+}
+
 __global__ __launch_bounds__(TPB) void scale_kernel(float *x, long n, float a) {
     long i = (long)blockIdx.x * TPB + threadIdx.x;
     const long stride = (long)gridDim.x * TPB;
@@ -1045,6 +1063,13 @@ int launch_fill_zero(hipStream_t s, float *p, long n) {
 int launch_prior_add(hipStream_t s, const float *d, float *q, int T, int na, int nb, float mu_reg) {
     dim3 grid((nb + TPB - 1) / TPB, na, T);
     hipLaunchKernelGGL(prior_add_kernel, grid, dim3(TPB), 0, s, d, q, na, nb, mu_reg);
+    return (int)hipGetLastError();
+}
+
+int launch_prior_joint_add(hipStream_t s, const float *d, float *q, int T, int na, int nb, float mu_reg) {
+    if (na < 3 || nb < 3) return (int)hipErrorInvalidValue;
+    dim3 grid((nb + TPB - 1) / TPB, na, T);
+    hipLaunchKernelGGL(prior_joint_add_kernel, grid, dim3(TPB), 0, s, d, q, na, nb, mu_reg);
     return (int)hipGetLastError();
 }
 

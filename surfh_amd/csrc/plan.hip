@@ -159,6 +159,7 @@ struct surfh_plan {
     // surfh_config.verify: every long sum accumulated in float64 (dense DFT products, spectral blur, adjoint spectral mix,
     // gather / scatter rows) -- the strict dot test; storage stays fp32
     bool verify = false;
+    int prior_kind = 0;                          // 0: separated first differences (NpDiff_r / NpDiff_c); 1: joint Laplacian (surfh_set_prior)
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
@@ -631,6 +632,11 @@ void build_dft(const surfh_plan *p, std::vector<float> &Fi, std::vector<float> &
             GfT[((size_t)0 * KBP + k) * NBP + b] = (float)c;
             GfT[((size_t)1 * KBP + k) * NBP + b] = (float)(-s);
         }
+}
+
+// q += mu_reg * (the plan's regulariser) d, per image of n_img
+int prior_add(surfh_plan *p, hipStream_t st, const float *d, float *q, int n_img, float mu_reg) {
+    return p->prior_kind == 1 ? launch_prior_joint_add(st, d, q, n_img, p->Na, p->Nb, mu_reg) : launch_prior_add(st, d, q, n_img, p->Na, p->Nb, mu_reg);
 }
 
 // fp32-MFMA GEMM, or its float64-accumulating twin in verification mode
@@ -1668,7 +1674,13 @@ int surfh_prior_add_dev(surfh_plan *p, const float *d, float *q, double mu_reg) 
     if (p->T <= 0) return fail("prior is defined on abundance maps (needs templates)");
     HIP_OK(hipSetDevice(p->dev));
     Prof pr(p, "prior_add");
-    LAUNCH_OK(launch_prior_add(p->stream, d, q, p->T, p->Na, p->Nb, (float)mu_reg));
+    LAUNCH_OK(prior_add(p, p->stream, d, q, p->T, (float)mu_reg));
+    return 0;
+}
+int surfh_set_prior(surfh_plan *p, int32_t kind) {
+    if (!p) return fail("null plan");
+    if (kind != 0 && kind != 1) return fail("prior kind %d: 0 = separated first differences, 1 = joint Laplacian", (int)kind);
+    p->prior_kind = kind;
     return 0;
 }
 int surfh_dot_dev(surfh_plan *p, const float *a, const float *b, int64_t n, double *out) {
@@ -1789,7 +1801,7 @@ int surfh_cg_cb(surfh_plan *p, const float *y, double mu, double mu_reg, const f
         if (normal_dev(p, v, out, mu)) return 1;
         if (mu_reg != 0.0) {
             Prof pr(p, "prior_add");
-            LAUNCH_OK(launch_prior_add(s, v, out, p->T, p->Na, p->Nb, (float)mu_reg));
+            LAUNCH_OK(prior_add(p, s, v, out, p->T, (float)mu_reg));
         }
         return 0;
     };
@@ -1871,7 +1883,7 @@ int surfh_mmmg(surfh_plan *p, const float *y, double mu, double mu_reg, const fl
         if (normal_dev(p, v, out, mu)) return 1;
         if (mu_reg != 0.0) {
             Prof pr(p, "prior_add");
-            LAUNCH_OK(launch_prior_add(s, v, out, p->T, p->Na, p->Nb, (float)mu_reg));
+            LAUNCH_OK(prior_add(p, s, v, out, p->T, (float)mu_reg));
         }
         return 0;
     };
@@ -1939,9 +1951,11 @@ int surfh_mmmg(surfh_plan *p, const float *y, double mu, double mu_reg, const fl
 }
 
 // ---- CG on independent planes: the 2-D deconvolution path (criterion_2D.py:60-250 per image, batched over wavelength)
-int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
-                    int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+int surfh_cg_planes_cb(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+                       int32_t refresh, float *x, double *grad_norm, int32_t *nit, surfh_cg_callback callback, void *user) {
     if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
+    std::vector<float> hx;             // host copy of the iterate handed to the callback
+    if (callback) hx.resize((size_t)p->isize);
     if (p->T != 0) return fail("surfh_cg_planes is the solver of the plane-wise (no template) model; use surfh_cg with templates");
     if (p->ch.empty()) return fail("plan has no channel");
     HIP_OK(hipSetDevice(p->dev));
@@ -1955,7 +1969,7 @@ int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, con
     auto done = [&](int rc) { hipFree(sc); return rc; };
     auto Q = [&](const float *v, float *out) -> int {
         if (normal_dev(p, v, out, mu)) return 1;
-        if (mu_reg != 0.0) LAUNCH_OK(launch_prior_add(s, v, out, L, p->Na, p->Nb, (float)mu_reg));
+        if (mu_reg != 0.0) LAUNCH_OK(prior_add(p, s, v, out, L, (float)mu_reg));
         return 0;
     };
     if (hipMemcpyAsync(p->io_y, y, p->osize * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail("copy failed"));
@@ -1990,6 +2004,13 @@ int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, con
         if (!rc) rc = (int)hipStreamSynchronize(s);
         if (rc) return done(fail("cg iteration failed: %s", hipGetErrorString((hipError_t)rc)));
         *nit = it + 1;
+        if (callback) {      // qmm.lcg's per-iteration callback (criterion_2D.py:163-225): trace so far [it + 2][L], current iterate
+            if (hipMemcpyAsync(hx.data(), p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                return done(fail("copy failed"));
+            if (callback(user, it + 1, grad_norm, hx.data())) break;
+            if (hipSetDevice(p->dev) != hipSuccess) return done(fail("hipSetDevice failed"));
+        }
         double worst = 0.0;
         for (int l = 0; l < L; ++l) worst = std::max(worst, gn[l]);
         if (std::sqrt(worst) < (double)npix * tol) break;
@@ -2000,11 +2021,18 @@ int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, con
     return done(0);
 }
 
+int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+                    int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+    return surfh_cg_planes_cb(p, y, mu, mu_reg, x0, max_iter, tol, refresh, x, grad_norm, nit, nullptr, nullptr);
+}
+
 // ---- 3MG on independent planes: what `method = "qmm"` of the 2-D deconvolution driver runs
 // (scripts/deconvolution_mrs_noRotation.py:199-212 -> criterion_2D.py:190-193 -> qmm.mmmg); see surfh_mmmg for the scheme.
-int surfh_mmmg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
-                      int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+int surfh_mmmg_planes_cb(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+                         int32_t refresh, float *x, double *grad_norm, int32_t *nit, surfh_cg_callback callback, void *user) {
     if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
+    std::vector<float> hx;
+    if (callback) hx.resize((size_t)p->isize);
     if (p->T != 0) return fail("surfh_mmmg_planes is the solver of the plane-wise (no template) model; use surfh_mmmg with templates");
     if (p->ch.empty()) return fail("plan has no channel");
     HIP_OK(hipSetDevice(p->dev));
@@ -2020,7 +2048,7 @@ int surfh_mmmg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, c
     auto done = [&](int rc) { hipFree(sc); return rc; };
     auto Q = [&](const float *v, float *out) -> int {
         if (normal_dev(p, v, out, mu)) return 1;
-        if (mu_reg != 0.0) LAUNCH_OK(launch_prior_add(s, v, out, L, p->Na, p->Nb, (float)mu_reg));
+        if (mu_reg != 0.0) LAUNCH_OK(prior_add(p, s, v, out, L, (float)mu_reg));
         return 0;
     };
     if (hipMemcpyAsync(p->io_y, y, p->osize * sizeof(float), hipMemcpyHostToDevice, s) != hipSuccess) return done(fail("copy failed"));
@@ -2046,6 +2074,13 @@ int surfh_mmmg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, c
             gn[l] = std::sqrt(gn[l]);
             worst = std::max(worst, gn[l]);
         }
+        if (it > 0 && callback) {
+            if (hipMemcpyAsync(hx.data(), p->cg_x, n * sizeof(float), hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess)
+                return done(fail("copy failed"));
+            if (callback(user, it, grad_norm, hx.data())) break;
+            if (hipSetDevice(p->dev) != hipSuccess) return done(fail("hipSetDevice failed"));
+        }
         if (it >= max_iter || worst < (double)npix * tol) break;
         if (Q(d, qd)) return done(1);
         const bool fresh = refresh > 0 && it % refresh == 0;
@@ -2062,6 +2097,11 @@ int surfh_mmmg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, c
     if (!rc) rc = (int)hipStreamSynchronize(s);
     if (rc) return done(fail("copy failed"));
     return done(0);
+}
+
+int surfh_mmmg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
+                      int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
+    return surfh_mmmg_planes_cb(p, y, mu, mu_reg, x0, max_iter, tol, refresh, x, grad_norm, nit, nullptr, nullptr);
 }
 
 // ---- drivers' LMM helpers on the device (spectroModel.py:187-198) -----------------------------

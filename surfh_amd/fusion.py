@@ -31,9 +31,15 @@ class OptimizeResult:
 
 class QuadCriterion_MRS:
     def __init__(self, mu_spectro, y_spectro, model_spectro, mu_reg, printing=False, gradient="separated"):
+        """``gradient="joint"`` regularises with the Laplacian of ``Difference_Operator_Joint`` (fusion_CT.py:45-62); udft's
+        ``laplacian(2)`` is absent from the reference tree, the 3 x 3 kernel [[0,-1,0],[-1,4,-1],[0,-1,0]] is restated: parity
+        unpinned for that option (the operator is checked against the oracle's Fourier-domain form of the same kernel).
+        NOTE on the data term: ``model_spectro.adjoint`` is the exact transpose of ``forward`` (what CG needs); the reference
+        hands qmm its interpolating ``gridding_t`` adjoint instead (spectroModel.py:173-185), so its right-hand side
+        mu A_ref^T y and hence its iterates differ from the ones computed here (tests/test_gpu_driver.py records by how much)."""
         assert isinstance(mu_reg, (float, int, list, np.ndarray))
-        if gradient != "separated":
-            raise NotImplementedError("only the separated first-difference priors (NpDiff_r / NpDiff_c) are built")
+        if gradient not in ("separated", "joint"):
+            raise ValueError(f"gradient must be 'separated' or 'joint', not {gradient!r}")
         self.mu_spectro, self.y_spectro, self.model_spectro, self.mu_reg = mu_spectro, y_spectro, model_spectro, mu_reg
         self.n_spec = model_spectro.ishape[0]
         self.shape_of_output = tuple(model_spectro.ishape)
@@ -50,6 +56,7 @@ class QuadCriterion_MRS:
         criterion of every iterate is recorded in ``L_crit_val`` instead."""
         assert isinstance(self.mu_reg, (int, float))       # fusion_CT.py:119
         solver = self.model_spectro.cg if method == "lcg" else self.model_spectro.mmmg     # fusion_CT.py:194-198
+        self.model_spectro.set_prior(self.gradient)                                         # fusion_CT.py:141-162
         if isinstance(value_init, (int, float)):
             init = np.ones(self.shape_of_output) * value_init
         else:
@@ -97,6 +104,9 @@ class QuadCriterion_MRS:
         """(mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2)) / 2   (fusion_CT.py:242-265)."""
         x_hat = np.asarray(x_hat).reshape(self.shape_of_output)
         data = self.mu_spectro * np.sum((self.y_spectro - self.model_spectro.forward(x_hat)) ** 2)
+        if self.gradient == "joint":                 # |D x|^2, D = circular 3 x 3 Laplacian centred on the pixel (:254-255, :45-54)
+            dx = 4 * x_hat - np.roll(x_hat, 1, 1) - np.roll(x_hat, -1, 1) - np.roll(x_hat, 1, 2) - np.roll(x_hat, -1, 2)
+            return (data + self.mu_reg * np.sum(dx ** 2)) / 2
         dr = np.roll(x_hat, 1, axis=1) - x_hat
         dc = np.roll(x_hat, 1, axis=2) - x_hat
         return (data + self.mu_reg * np.sum(dr ** 2 + dc ** 2)) / 2

@@ -273,6 +273,13 @@ class spectroSigRLSCT(LinOp):
     def residual_dev(self, r_t, b_t, q_t, n: int):
         _lib.check(self._L.surfh_residual_dev(self._plan, _ptr(r_t), _ptr(b_t), _ptr(q_t), int(n)))
 
+    def set_prior(self, gradient: str = "separated"):
+        """The regulariser of ``cg`` / ``mmmg`` / ``prior_add_dev``: "separated" (NpDiff_r / NpDiff_c, the default) or "joint"
+        (the Laplacian of Difference_Operator_Joint) -- ``QuadCriterion_MRS(gradient=...)``, fusion_CT.py:98-106."""
+        if gradient not in ("separated", "joint"):
+            raise ValueError(f"gradient must be 'separated' or 'joint', not {gradient!r}")
+        _lib.check(self._L.surfh_set_prior(self._plan, 1 if gradient == "joint" else 0))
+
     # ---- solver on one GPU ------------------------------------------------------------------
     def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):
         """Device-resident linear CG (qmm.lcg restated).  ``callback(it, grad_norm, x)`` -- the per-iteration callback

@@ -172,19 +172,20 @@ class MRSBlurred(LinOp):
         return self._call(self._L.surfh_adjoint, data, self.osize, self.ishape)
 
     # ---- solver: regularised least squares by CG, one independent 2-D problem per plane -------------------
-    def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+    def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):
         """Device-resident linear CG on  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2)  (criterion_2D.py:60-250 with
         `qmm.lcg` restated).  Batched model: every plane is its own problem with its own step sizes; returns
-        ``(x, grad_norm, nit)`` with ``grad_norm`` of shape ``[nit+1]`` (single image) or ``[nit+1, n_planes]``."""
-        return self._solve(self._L.surfh_cg_planes, data, mu, mu_reg, x0, max_iter, tol, refresh)
+        ``(x, grad_norm, nit)`` with ``grad_norm`` of shape ``[nit+1]`` (single image) or ``[nit+1, n_planes]``.
+        ``callback(it, grad_norm, x)`` as for ``spectroSigRLSCT.cg``."""
+        return self._solve(self._L.surfh_cg_planes_cb, data, mu, mu_reg, x0, max_iter, tol, refresh, callback)
 
-    def mmmg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50):
+    def mmmg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):
         """Device-resident 3MG on the same criterion (`qmm.mmmg` restated for quadratic objectives) -- what the 2-D
         deconvolution driver's ``method = "qmm"`` runs (scripts/deconvolution_mrs_noRotation.py:199-212).  Same returns as
         ``cg`` except that ``grad_norm`` holds |grad| (not squared)."""
-        return self._solve(self._L.surfh_mmmg_planes, data, mu, mu_reg, x0, max_iter, tol, refresh)
+        return self._solve(self._L.surfh_mmmg_planes_cb, data, mu, mu_reg, x0, max_iter, tol, refresh, callback)
 
-    def _solve(self, fn, data, mu, mu_reg, x0, max_iter, tol, refresh):
+    def _solve(self, fn, data, mu, mu_reg, x0, max_iter, tol, refresh, callback=None):
         y = np.ascontiguousarray(np.asarray(data, dtype=np.float32).reshape(-1))
         if y.size != self.osize:
             raise ValueError("data size mismatch")
@@ -194,9 +195,23 @@ class MRSBlurred(LinOp):
         x = np.empty(self.isize, dtype=np.float32)
         gn = np.zeros((max_iter + 1, self.n_planes), dtype=np.float64)
         nit = C.c_int32()
+        err = []
+
+        def tramp(_user, it, gptr, xptr):
+            try:
+                g = np.ctypeslib.as_array(gptr, shape=(it + 1, self.n_planes)).copy()
+                xi = np.ctypeslib.as_array(xptr, shape=(self.isize,)).astype(np.float64).reshape(self.ishape)
+                return 1 if callback(it, g if self.batched else g[:, 0], xi) else 0
+            except BaseException as e:          # never unwind through the C frame
+                err.append(e)
+                return 1
+
+        cb = _lib.CG_CALLBACK(tramp) if callback is not None else _lib.CG_CALLBACK()
         _lib.check(fn(self._plan, _lib.fptr(y), float(mu), float(mu_reg),
                       _lib.fptr(x0a) if x0a is not None else None, int(max_iter), float(tol), int(refresh),
-                      _lib.fptr(x), _lib.dptr(gn), C.byref(nit)))
+                      _lib.fptr(x), _lib.dptr(gn), C.byref(nit), cb, None))
+        if err:
+            raise err[0]
         gn = gn[: nit.value + 1]
         return x.astype(np.float64).reshape(self.ishape), (gn if self.batched else gn[:, 0]).copy(), nit.value
 
@@ -217,15 +232,42 @@ class QuadCriterion_MRS_2D:
     def run_method(self, method="lcg", maximum_iterations=10, tolerance=1e-12, calc_crit=False, perf_crit=None, value_init=0.5):
         assert isinstance(self.mu_reg, (int, float))             # criterion_2D.py:115
         solver = self.model_spectro.cg if method == "lcg" else self.model_spectro.mmmg       # criterion_2D.py:190-193
-        if calc_crit or perf_crit is not None:
-            raise NotImplementedError("per-iteration callbacks are built for the fusion criterion (QuadCriterion_MRS) only")
         init = np.ones(self.shape_of_output) * value_init if isinstance(value_init, (int, float)) else value_init
         assert tuple(np.shape(init)) == self.shape_of_output
         import time
         from .fusion import OptimizeResult
+        self.L_crit_val = []
+        self.it = 1
+
+        # the four callback modes of criterion_2D.py:163-225 (the same as fusion_CT.py:163-225, see QuadCriterion_MRS.run_method)
+        def record_crit(x):
+            crit_val = self.get_crit_val(x)
+            self.L_crit_val.append(crit_val)
+            print(f"Criterion value = {crit_val}\n")
+
+        def print_last_grad_norm(it, gn, x):
+            print(f"Iteration n°{self.it}, Grad norm = {np.max(np.atleast_1d(gn[-1]))}")
+            self.it = self.it + 1
+
+        def print_last_grad_norm_and_crit(it, gn, x):
+            print_last_grad_norm(it, gn, x)
+            if self.it % 5 == 2:
+                record_crit(x)
+
+        if calc_crit and perf_crit is None:
+            print(f"{method} : Criterion calculated at each iteration!")
+            callback = lambda it, gn, x: record_crit(x)      # noqa: E731
+        elif not calc_crit and perf_crit is not None:
+            print(f"{method} : perf_crit calculated at each iteration!")
+            callback = print_last_grad_norm
+        elif calc_crit and perf_crit is not None:
+            print(f"{method} : criterion and gradient printed at each iteration!")
+            callback = print_last_grad_norm_and_crit
+        else:
+            callback = None
         t0 = time.time()
         x, gn, nit = solver(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
-                            max_iter=maximum_iterations, tol=tolerance)
+                            max_iter=maximum_iterations, tol=tolerance, callback=callback)
         last = np.max(np.atleast_1d(gn[-1]))
         last = np.sqrt(last) if method == "lcg" else last           # lcg traces r.r, mmmg |grad|
         res = OptimizeResult(x=x.ravel(), grad_norm=list(gn), nit=nit,

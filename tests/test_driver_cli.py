@@ -48,3 +48,19 @@ def test_load_data_from_npz(tmp_path):
         assert dd["rotation"][chan] == 251.0 and dd["target"][chan][1] == (1e-4, -2e-4)
     ifus = drv.create_instruments(dd, ["1a", "2a"])
     assert ifus["2a"].n_slit == 17 and ifus["2a"].fov.angle == -251.0 and ifus["1a"].n_wavel == 1050
+
+
+def test_deconvolution_driver_command_line():
+    """scripts/deconvolution_mrs.py: the reference run's parameters are the defaults
+    (scripts/simulate_deconvolution_mrs_rectangle.py:183-198: lcg, 600 iterations, mu_reg 5, value_init 0)."""
+    sp = importlib.util.spec_from_file_location("deconvolution_mrs", os.path.join(ROOT, "scripts", "deconvolution_mrs.py"))
+    dd = importlib.util.module_from_spec(sp)
+    sp.loader.exec_module(dd)
+    r = CliRunner().invoke(dd.main, ["--help"])
+    assert r.exit_code == 0
+    defaults = {p.name: p.default for p in dd.main.params}
+    assert defaults["niter"] == 600 and defaults["hyper_parameter"] == 5.0 and defaults["method"] == "lcg" and defaults["value_init"] == 0.0
+    prob = dd.build_problem(96, 1, 1, None)
+    assert prob["sotf"].shape == (96, 49) and prob["truth"].shape == (96, 96) and len(prob["pointings"]) == 4
+    prob3 = dd.build_problem(64, 3, 1, None)
+    assert prob3["sotf"].shape == (3, 64, 33) and prob3["truth"].shape == (3, 64, 64)
