@@ -79,7 +79,18 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-verify", action="store_true", help="skip the randn dot test on the float64-accumulating verification plan")
+    ap.add_argument("--plan-only", action="store_true", help="no GPU: print the unit assignment and the predicted per-rank cost "
+                    "imbalance for --gpus N on the chosen config (gate <= 15 %%, SURVEY.md 8e) and exit")
     args = ap.parse_args()
+    if args.plan_only:
+        from surfh_amd import synth
+        from surfh_amd.fusion import plan_assignment
+        prob = (synth.config2 if args.config == "2" else synth.config3)(geometry_only=True)
+        asg, loads, imb = plan_assignment(prob, args.gpus)
+        print(json.dumps({"config": args.config, "n_gpus": args.gpus, "assignment": repr(asg),
+                          "predicted_us_per_iteration_per_rank": [round(v, 1) for v in loads], "imbalance": round(imb, 4),
+                          "gate": 0.15, "ok": bool(imb <= 0.15)}))
+        return
 
     import torch
     import torch.distributed as dist

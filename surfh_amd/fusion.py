@@ -213,6 +213,30 @@ def partition_units(costs: Sequence[float], n_pointings: Sequence[int], world: i
     return out
 
 
+def plan_assignment(prob: dict, world: int, split: str = "lambda"):
+    """The unit assignment ``DistributedFusion`` uses for `world` ranks, with the predicted cost of every rank:
+    ``(assignment, loads, imbalance)``, imbalance = max load / mean load - 1 (SURVEY.md 8e gate: <= 15 %).  Host only."""
+    from .geometry import ChannelGeometry
+    ifus, pts = prob["ifus"], prob["pointings"]
+    n_pix = len(prob["alpha_axis"])
+    srfs = instru.get_srf([i.det_pix_size for i in ifus], prob["step_deg"] * 3600)
+    geos = [ChannelGeometry(i, prob["alpha_axis"], prob["beta_axis"], prob["wavel"], s, p, prob["step_deg"])
+            for i, s, p in zip(ifus, srfs, pts)]
+    costs = [band_cost(n_pix, g) for g in geos]
+    if split == "lambda":
+        lins = [g.wslice.stop - g.wslice.start for g in geos]
+        share = lambda k, u: costs[k] * (1.0 if u == (0, 1) else ((u[2] - u[1]) / lins[k] if len(u) == 3 else 1.0 / u[1]))   # noqa: E731
+        cand, bal = partition_lambda(costs, world), partition_balanced(costs, lins, world)
+        load = lambda asg: [sum(share(k, u) for k, u in r) for r in asg]                                                   # noqa: E731
+        asg = cand if max(load(cand)) <= 1.05 * max(load(bal)) else bal
+        loads = load(asg)
+    else:
+        asg = partition_units(costs, [len(p) for p in pts], world)
+        loads = [sum(costs[k] * len(sel) / len(pts[k]) for k, sel in r) for r in asg]
+    mean = sum(loads) / len(loads)
+    return asg, loads, max(loads) / mean - 1.0
+
+
 class DistributedFusion:
     """One rank of the channel-sharded CG.  ``prob`` is a dict as produced by ``surfh_amd.synth.problem``."""
 

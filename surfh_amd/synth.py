@@ -98,12 +98,16 @@ def dither4(ifu: instru.IFU) -> instru.CoordList:
     return instru.CoordList([instru.Coord(da, db), instru.Coord(-da, db), instru.Coord(da, -db), instru.Coord(-da, -db)])
 
 
-def problem(bands: Sequence[str], n_lambda: int, lam_range, n_pix: int = 251, lam_stride: int = 1) -> dict:
+def problem(bands: Sequence[str], n_lambda: int, lam_range, n_pix: int = 251, lam_stride: int = 1, geometry_only: bool = False) -> dict:
     """A fusion problem on an n_pix^2 x n_lambda cube observed by `bands` with the 4-point dither.
-    ``lam_stride`` > 1 keeps every lam_stride-th cube plane (CPU-baseline sample)."""
+    ``lam_stride`` > 1 keeps every lam_stride-th cube plane (CPU-baseline sample); ``geometry_only`` leaves out the arrays
+    (OTF, templates, maps) -- enough to plan the multi-GPU partition."""
     wav = np.linspace(lam_range[0], lam_range[1], n_lambda)[::lam_stride]
     ax = axes(n_pix)
     ifus = [band_ifu(b) for b in bands]
+    if geometry_only:
+        return dict(bands=list(bands), alpha_axis=ax, beta_axis=ax.copy(), wavel=wav, ifus=ifus,
+                    pointings=[dither4(i) for i in ifus], step_deg=STEP_DEG)
     return dict(bands=list(bands), alpha_axis=ax, beta_axis=ax.copy(), wavel=wav, ifus=ifus,
                 pointings=[dither4(i) for i in ifus], templates=templates(n_lambda)[:, ::lam_stride],
                 sotf=ir2fr(gaussian_psf(wav, STEP), (n_pix, n_pix)), step_deg=STEP_DEG,

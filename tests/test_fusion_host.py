@@ -44,3 +44,30 @@ def test_band_wavelength_tables_are_the_reference_tables():
     p3 = synth.config3(lam_stride=500)
     lo, hi, n = g["axis_cfg3"]
     assert np.array_equal(np.linspace(lo, hi, int(n))[::500], p3["wavel"])
+
+
+def test_partition_imbalance_gate():
+    """the assignment the multi-GPU driver will use for 2, 4 and 8 ranks on config 3 (4 bands) and for 8 ranks on
+    config 4 (12 bands, npix 501): every cube plane of every band owned exactly once, predicted per-rank cost within 15 %."""
+    from surfh_amd.fusion import plan_assignment
+    p3 = synth.config3(geometry_only=True)
+    p4 = synth.config4(n_pix=501, geometry_only=True)
+    for prob, worlds in ((p3, (2, 4, 8)), (p4, (2, 4, 8))):
+        for world in worlds:
+            asg, loads, imb = plan_assignment(prob, world)
+            print(len(prob["ifus"]), "bands on", world, "ranks: loads", [round(v) for v in loads], f"imbalance {imb:.3f}")
+            assert len(asg) == world and all(len(r) > 0 for r in asg)
+            assert imb <= 0.15, (world, loads)
+            # coverage: the lambda parts of every band tile its window exactly
+            from surfh_amd.geometry import ChannelGeometry
+            from surfh_amd import instru
+            for k in range(len(prob["ifus"])):
+                parts = [u for r in asg for kk, u in r if kk == k]
+                assert parts, k
+                if parts == [(0, 1)]:
+                    continue
+                if len(parts[0]) == 3:        # ("planes", a, b)
+                    iv = sorted((u[1], u[2]) for u in parts)
+                    assert iv[0][0] == 0 and all(iv[i][1] == iv[i + 1][0] for i in range(len(iv) - 1))
+                else:                          # (i, n) equal parts
+                    assert sorted(u[0] for u in parts) == list(range(parts[0][1]))
