@@ -230,6 +230,10 @@ def main():
                     return "gemm_nt_bf16x3_pc_kernel"
                 cc = os.environ.get("SURFH_WBLUR_CC", "2")
                 return "gemm_nt_f16x2_cc_kernel" if (cc == "2" or (cc == "1" and name.endswith("adj"))) else "gemm_nt_f16x2_pc_kernel"
+            if name.startswith("specmix_"):       # interleaved spectra where the two-piece fp16 passes run (dft_h2.hip)
+                return name + ("_ilv_kernel" if any(k.startswith("dft_h2_") for k in prof_all) else "_kernel")
+            if name.startswith("dft_h2_"):
+                return "dft_h2_kernel"             # four template instances <KIND, MIX> of one kernel (dft_h2.hip)
             if name.startswith("dft_rx3_"):
                 return "dft_rx3_kernel"            # four template instances <KIND, MIX> of one kernel (dft_rx3.hip)
             if name.startswith("dft_fold_cols"):
@@ -285,7 +289,7 @@ def main():
                 # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
                 # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel
                 # (complex pass) and one of dft_fold_kernel (real pass): half of a transform's bytes per launch.
-                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith(("dft_fold", "dft_rx3")) else None
+                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith(("dft_fold", "dft_rx3", "dft_h2")) else None
                 ach = bytes_launch / avg_s / 1e9 if bytes_launch else None
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic, "kernel": dom,
@@ -295,7 +299,7 @@ def main():
                       else "CG-iterations/sec (forward+adjoint) on 251x251x1024 cube",
             "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32 (storage and accumulation; products as 2-piece fp16 splits in the spectral-blur GEMM and 3-piece bf16 splits in the DFT passes, on the 16-bit matrix cores)", "data": "synthetic",
+            "dtype": "f32 (storage and accumulation; products as 2-piece fp16 splits -- 3 products per fp32 product -- on the 16-bit matrix cores, in the spectral-blur GEMM and in the DFT passes)", "data": "synthetic",
             "config": {"workload": ("config3: 4 MRS bands 1C,2A,2B,2C, 251x251x4000 cube, 4-point dither, T=4, mu_reg=5e3"
                                     if args.config == "3" else
                                     "config2: band 2A, 251x251x1024 cube, 4-point dither, T=4, mu_reg=5e3"),
@@ -307,7 +311,7 @@ def main():
         }
         # the HBM-bound half of the path, whichever kernel group dominates: the four DFT passes of a step against the
         # algorithmic bytes of its two 2-D transforms (FFT-conv stage)
-        dft = [(k, v) for k, v in (groups if dom_prefix == "dft_" else groups_all).items() if k.startswith(("dft_rx3", "dft_fold"))]
+        dft = [(k, v) for k, v in (groups if dom_prefix == "dft_" else groups_all).items() if k.startswith(("dft_rx3", "dft_fold", "dft_h2"))]
         if dft:
             n_l = sum(v[0] for _, v in dft)
             t_s = sum(v[1] for _, v in dft) * 1e-3
@@ -315,7 +319,7 @@ def main():
             out["roofline_fft_conv_stage"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": ach / HBM_PEAK_GBS, "kernel": "+".join(sorted(k for k, _ in dft)),
                                               "launches": n_l, "avg_ms": t_s * 1e3 / n_l,
-                                              "traffic": pmc.get("dft_rx3_kernel", {}).get("hbm_bytes_per_launch")}
+                                              "traffic": pmc.get(dft[0][0], {}).get("hbm_bytes_per_launch")}
         # the matrix-core half of the path, whichever group dominates: R / R^T against the fp32-MFMA peak
         gm = [(k, v) for k, v in (groups if dom_prefix == "gemm_wblur" else groups_all).items() if k.startswith("gemm_nt")]
         if gm:

@@ -1,0 +1,408 @@
+// Two-piece fp16 DFT pass with LDS-resident matrices, decoupled waves and interleaved complex arrays (see dft_h2.h).
+// One persistent workgroup of eight waves per CU; a wave owns all 128 output rows of its 32 lane-columns (32 real
+// columns, or 16 complex columns x 2 components), i.e. 2 products x 4 row tiles x 16 = 128 accumulator registers,
+// and walks its own sequence of tiles: after the initial copy of the matrix image there is no workgroup barrier
+// (the fused spectral mix adds one per change of k_beta).  Each wave pipelines its stream of k-steps: raw loads two
+// steps ahead, fold / scale / split one step ahead, MFMAs on the current step; a tile's stores are issued after its
+// last MFMA group, behind loads that are already in flight.
+#include "dft_h2.h"
+#include "lds_attr.h"
+#include <cmath>
+#include <cstring>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#ifndef H2_EXP
+#define H2_EXP 0        // tools/exp: 2 no stores, 4 no MFMAs, 8 no loads
+#endif
+
+namespace {
+
+constexpr int BK = 16, RS = 16;
+constexpr int PIECE = 128 * RS;                       // halfs of one (matrix, piece, k-step) block: 4 KB
+constexpr int KT = DFT_H2_KT;
+constexpr int IMG_HALFS = (int)DFT_H2_IMAGE_HALFS;    // 65536 halfs = 128 KB
+constexpr int MIX_ROWS = 256;                         // rows of one spectral-mix table ([k][re/im] float4): 8 KB
+constexpr size_t LDS_IMG = (size_t)IMG_HALFS * 2;
+constexpr size_t LDS_MIX = (size_t)2 * MIX_ROWS * 2 * sizeof(float4);
+constexpr int NTHREADS = 512, NWAVES = 8;
+constexpr int E_TARGET = 10, E_LIMIT = 15;            // a column's largest scaled magnitude: set below 2^10, rescaled at 2^15
+
+#define MFMA3(acc_, ah_, al_, bh_, bl_)                                             \
+    {                                                                               \
+        f32x16 c_ = acc_;                                                           \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(al_, bh_, c_, 0, 0, 0);         \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bl_, c_, 0, 0, 0);         \
+        c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah_, bh_, c_, 0, 0, 0);         \
+        acc_ = c_;                                                                  \
+    }
+
+// 8 scaled values -> (hi, lo) fp16 fragments
+__device__ __forceinline__ void split8h(const float (&x)[8], int e, f16x8 &fh, f16x8 &fl) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float xs = __builtin_amdgcn_ldexpf(x[j], e);
+        const _Float16 hh = (_Float16)xs;
+        fh[j] = hh;
+        fl[j] = (_Float16)(xs - (float)hh);
+    }
+}
+
+// the value held by the neighbouring lane (lane ^ 1): the other component of the same complex column
+__device__ __forceinline__ float pair_swap(float x) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, false));
+}
+
+template <int KIND, bool MIX>
+__global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uint4 *__restrict__ img, int kA, int NS, long NT) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform: tile indices and descriptors stay scalar
+    const int l31 = lane & 31, h = lane >> 5;
+    constexpr int TNW = (KIND == 0) ? 16 : 32;                 // columns of a wave tile (complex columns for kind 0)
+    constexpr int SRC_T = (KIND == 2) ? 64 : 32, DST_T = (KIND == 1) ? 64 : 32;   // floats of a tile's row segment
+    const int var = (KIND == 0) ? (l31 & 1) : 0;               // kind 0: the component this lane owns
+    const int lcol = (KIND == 0) ? (l31 >> 1) : l31;
+    const int tilesX = g.N / TNW;
+    const unsigned ldb4 = (unsigned)(g.ldb * 4), ldc4 = (unsigned)(g.ldc * 4);
+    const unsigned c4 = (unsigned)l31 * (KIND == 2 ? 8u : 4u), d4 = (unsigned)l31 * (KIND == 1 ? 8u : 4u);
+    const int nk = g.KP / BK;
+    const int kin = g.Kn / 2 + 1;
+    float4 *mixbuf = reinterpret_cast<float4 *>(lds + IMG_HALFS);
+
+    // the matrix image: global -> LDS, once
+    {
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < IMG_HALFS / 8; i += NTHREADS) l4[i] = img[i];
+    }
+    // this workgroup's contiguous range of super-tiles (8 wave tiles each); wave w takes tile 8 s + w
+    const int s0 = (int)((long)NS * blockIdx.x / gridDim.x), s1 = (int)((long)NS * (blockIdx.x + 1) / gridDim.x);
+    int ntw = s1 - s0;
+    if (ntw > 0 && (long)8 * (s1 - 1) + wave >= NT) --ntw;
+
+    // fused spectral mix: the (k, kb) column of mhat, all k, as [k][re/im] x 4 templates in LDS, one table per kb parity
+    const float4 *mtab = mixbuf;
+    float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
+    int mix_kb = -1;
+#define H2_MIXTAB(kb_)                                                                                          \
+    {                                                                                                           \
+        float4 *mt_ = mixbuf + ((kb_) & 1) * (MIX_ROWS * 2);                                                     \
+        const int ne = (g.Kn > g.KP ? g.Kn : g.KP) * 2;                                                         \
+        for (int e_ = tid; e_ < ne; e_ += NTHREADS) {                                                           \
+            const int k = e_ >> 1, c = e_ & 1;                                                                  \
+            float v[4];                                                                                         \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                       \
+                v[t] = (t < g.T && k < g.Kn) ? g.mhat[((long)t * 2 + c) * g.PL + (long)k * g.KBP + (kb_)] : 0.f; \
+            mt_[e_] = make_float4(v[0], v[1], v[2], v[3]);                                                      \
+        }                                                                                                       \
+        mtab = mt_;                                                                                             \
+        mix_kb = (kb_);                                                                                         \
+    }
+    // per-tile state of the fold (MIX only): template weights of this lane's wavelength, table of the tile's kb;
+    // a change of kb is reached by all eight waves of the workgroup (same tile sequence): the table buffer of parity
+    // kb & 1 was last read two values of kb ago, i.e. before the previous barrier
+#define H2_FSETUP(t_)                                                                                           \
+    if (MIX) {                                                                                                  \
+        const int fn0 = ((t_) % tilesX) * TNW;                                                                   \
+        const int kb = fn0 / g.LP, l = (fn0 % g.LP) + lcol;                                                     \
+        float t4[4];                                                                                            \
+        _Pragma("unroll") for (int t = 0; t < 4; ++t) t4[t] = (t < g.T) ? g.tpl[(long)t * g.LP + l] : 0.f;      \
+        tw = make_float4(t4[0], t4[1], t4[2], t4[3]);                                                           \
+        if (kb != mix_kb) {                                                                                     \
+            H2_MIXTAB(kb);                                                                                      \
+            __syncthreads();                                                                                    \
+        }                                                                                                       \
+    }
+
+    // Addressing: buffer loads / stores -- a descriptor per tile (scalar), the row as a 32-bit scalar byte offset, the
+    // lane part (k half, column) in one 32-bit VGPR: no 64-bit vector address arithmetic.  The launcher checks that
+    // every row offset of a tile fits in 32 bits.
+    __amdgpu_buffer_rsrc_t R0;
+#define H2_RSRC(ptr_) __builtin_amdgcn_make_buffer_rsrc((void *)(ptr_), 0, 0xFFFFFFFF, 0x00020000)
+#define H2_BLOAD(v_, s_) ((H2_EXP & 8) ? __uint_as_float((v_) + (s_)) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(R0, (int)(v_), (int)(s_), 0)))
+#define H2_BLOAD2(v_, s_) __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(R0, (int)(v_), (int)(s_), 0))
+#define H2_LSETUP(t_)                                                                                           \
+    {                                                                                                           \
+        const int tx = (t_) % tilesX;                                                                           \
+        const long bz_ = (t_) / tilesX;                                                                         \
+        R0 = H2_RSRC(g.src + bz_ * g.sB + (long)tx * SRC_T);                                                    \
+    }
+    // raw loads of this lane's 8 k of k-step kt_ (k = 16 kt + 8 h + j) and, for the folded kinds, of their mirror rows
+    // (Kn - k): branch-free, all in flight together.  The mirror is read unconditionally (zero weight where there is
+    // none), except k = 0 whose "mirror" row Kn may not exist
+#define H2_LOAD(kt_)                                                                                            \
+    {                                                                                                           \
+        const unsigned sk = (unsigned)((kt_) * BK) * ldb4, sp = (unsigned)(g.Kn - (kt_) * BK - 8) * ldb4;       \
+        const unsigned vk = (unsigned)(8 * hv) * ldb4 + c4, vp = (unsigned)(8 * (1 - hv)) * ldb4 + c4;          \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
+            if (KIND == 2) {                                                                                    \
+                const f32x2 v2 = H2_BLOAD2(vk, sk + (unsigned)j * ldb4);                                        \
+                xr[j] = v2[0];                                                                                  \
+                qr[j] = v2[1];                                                                                  \
+            } else {                                                                                            \
+                xr[j] = H2_BLOAD(vk, sk + (unsigned)j * ldb4);                                                  \
+                const unsigned q = (j == 0 && (kt_) == 0) ? c4 : vp;                                            \
+                qr[j] = H2_BLOAD(q, sp - (unsigned)j * ldb4);                                                   \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    // fold (and mix) the raw values into the two data streams of k-step kt_
+#define H2_FOLD(kt_)                                                                                            \
+    {                                                                                                           \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
+            if (KIND == 2) {                                                                                    \
+                x0[j] = xr[j];                                                                                  \
+                x1[j] = qr[j];                                                                                  \
+            } else {                                                                                            \
+                const int k = (kt_) * BK + 8 * hv + j;                                                          \
+                const bool pv = (k >= 1) && (k < kin) && (2 * k != g.Kn);                                       \
+                float a = xr[j], b = qr[j];                                                                     \
+                if (MIX) {      /* own component of (re + i im) * s: re' = re sr - im si, im' = im sr + re si */   \
+                    const float ap = pair_swap(a), bp = pair_swap(b);                                           \
+                    const int kp = pv ? g.Kn - k : k;                                                           \
+                    const float4 mr = mtab[2 * k], mi = mtab[2 * k + 1], nr = mtab[2 * kp], ni = mtab[2 * kp + 1]; \
+                    const float sr = tw.x * mr.x + tw.y * mr.y + tw.z * mr.z + tw.w * mr.w;                     \
+                    const float si = tw.x * mi.x + tw.y * mi.y + tw.z * mi.z + tw.w * mi.w;                     \
+                    const float ur = tw.x * nr.x + tw.y * nr.y + tw.z * nr.z + tw.w * nr.w;                     \
+                    const float ui = tw.x * ni.x + tw.y * ni.y + tw.z * ni.z + tw.w * ni.w;                     \
+                    a = a * sr + sgv * (ap * si);                                                               \
+                    b = b * ur + sgv * (bp * ui);                                                               \
+                }                                                                                               \
+                const float ev = a + (pv ? b : 0.f), od = pv ? a - b : 0.f;                                     \
+                x0[j] = ev;                                                                                     \
+                x1[j] = (KIND == 0) ? pair_swap(od) : od;      /* kind 0: the odd part of the other component */   \
+            }                                                                                                   \
+        }                                                                                                       \
+    }
+    // exponent p of this column's largest folded magnitude (|x| < 2^p), over both streams and both k halves
+#define H2_MAXEXP(p_)                                                                                           \
+    {                                                                                                           \
+        float m_ = 0.f;                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) m_ = fmaxf(m_, fmaxf(fabsf(x0[j]), fabsf(x1[j])));        \
+        const unsigned mu_ = __float_as_uint(m_);                                                               \
+        const auto sw_ = __builtin_amdgcn_permlane32_swap(mu_, mu_, false, false);                              \
+        m_ = fmaxf(m_, fmaxf(__uint_as_float(sw_[0]), __uint_as_float(sw_[1])));                                \
+        p_ = __builtin_amdgcn_frexp_expf(m_);                                                                   \
+    }
+#define H2_MFMA(m_, kt_, acc_, bh_, bl_)                                                                        \
+    {                                                                                                           \
+        const unsigned short *ra = lds + ((m_) * 2 * KT + (kt_)) * PIECE + l31 * RS + 8 * (h ^ ((l31 >> 3) & 1)); \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                      \
+            const unsigned short *p = ra + mt * 32 * RS;                                                        \
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(p);                                               \
+            const f16x8 al = *reinterpret_cast<const f16x8 *>(p + KT * PIECE);                                  \
+            if (!(H2_EXP & 4)) MFMA3(acc_[mt], ah, al, bh_, bl_)                                                \
+            else acc_[mt][0] += (float)bh_[mt] + (float)bl_[mt] + (float)ah[0] + (float)al[0];                  \
+        }                                                                                                       \
+    }
+
+    int hv = h;
+    const float sgv = var ? 1.f : -1.f;
+    float xr[8], qr[8];                // raw values: rows k and mirror rows (kind 2: re and im of rows k)
+    float x0[8], x1[8];
+    f16x8 c0h, c0l, c1h, c1l;          // fragments of the current k-step
+    f32x16 acc1[4], acc2[4];
+
+    if (MIX) {                         // first table (the barrier also publishes the matrix image)
+        if (ntw > 0) {
+            const int kb0 = (((8 * s0 + wave) % tilesX) * TNW) / g.LP;
+            H2_MIXTAB(kb0);
+        }
+    }
+    __syncthreads();
+    if (ntw <= 0) return;              // MIX: NT % 8 == 0, so all waves of a workgroup leave together
+
+    // Software pipeline over this wave's stream of k-steps.  Inside a step: MFMAs of the first matrix, fold of the next
+    // step's raw values, loads of the step after that, the first stream's fragments rebuilt in place, MFMAs of the
+    // second matrix, the second stream's fragments rebuilt.  At a tile seam the next tile's first two k-steps are
+    // requested before the stores of the epilogue.
+    int tile = 8 * s0 + wave;
+    const int tend = tile + NWAVES * ntw;              // this wave's tiles: tile, tile + 8, ... < tend
+    int e = 0, en = 0;                                  // block exponents of the current / next k-step's column
+
+    H2_LSETUP(tile);
+    H2_LOAD(0);
+    H2_FSETUP(tile);
+    H2_FOLD(0);
+    {
+        int p;
+        H2_MAXEXP(p);
+        e = E_TARGET - p;
+    }
+    split8h(x0, e, c0h, c0l);
+    split8h(x1, e, c1h, c1l);
+    H2_LOAD(1);
+    while (true) {
+        asm volatile("" : "+v"(hv));   // keeps the per-lane fold selectors from being hoisted out of the tile loop
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
+        const int next = tile + NWAVES;
+        const bool more = next < tend;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            H2_MFMA(0, kt, acc1, c0h, c0l);
+            H2_FOLD(kt + 1);           // raw holds k-step kt + 1 of this tile
+            int p;
+            H2_MAXEXP(p);
+            const bool need = p + e > E_LIMIT;
+            en = need ? E_TARGET - p : e;
+            const int d = en - e;
+            if (kt + 2 < nk) {
+                H2_LOAD(kt + 2);
+            } else if (more) {
+                H2_LSETUP(next);
+                H2_LOAD(0);
+            }
+            split8h(x0, en, c0h, c0l);
+            H2_MFMA(1, kt, acc2, c1h, c1l);
+            split8h(x1, en, c1h, c1l);
+            if (__builtin_amdgcn_ballot_w64(d != 0) != 0ull) {
+                // a column's next k-step would overflow its fp16 range: its accumulators move to the lower exponent
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc1[mt][r] = __builtin_amdgcn_ldexpf(acc1[mt][r], d);
+                        acc2[mt][r] = __builtin_amdgcn_ldexpf(acc2[mt][r], d);
+                    }
+            }
+            e = en;
+        }
+        // last k-step of the tile; raw holds k-step 0 of the next tile (if any)
+        H2_MFMA(0, nk - 1, acc1, c0h, c0l);
+        if (more) {
+            H2_FSETUP(next);
+            H2_FOLD(0);
+            int p;
+            H2_MAXEXP(p);
+            en = E_TARGET - p;         // fresh exponent: the next tile's accumulators start from zero
+            H2_LOAD(1);
+            split8h(x0, en, c0h, c0l);
+        }
+        H2_MFMA(1, nk - 1, acc2, c1h, c1l);
+        if (more) split8h(x1, en, c1h, c1l);
+        {
+            // epilogue: descriptor of the tile's destination, rows as running scalar offsets
+            const int tx = tile % tilesX;
+            const long bz = tile / tilesX;
+            const float f = __builtin_amdgcn_ldexpf(1.f, -e - kA);
+            const float e0 = f * (var ? g.e_alt[0] : g.e[0]), e1 = f * (var ? g.e_alt[1] : g.e[1]);
+            const float e2 = f * (var ? g.e_alt[2] : g.e[2]), e3 = f * (var ? g.e_alt[3] : g.e[3]);
+            const __amdgpu_buffer_rsrc_t W0 = H2_RSRC(g.dst + bz * g.sC + (long)tx * DST_T);
+            const unsigned lo = (unsigned)(4 * h) * ldc4 + d4, lm = (unsigned)(4 * (1 - h)) * ldc4 + d4;
+            unsigned sk0 = 0u, sm0 = (unsigned)(g.Rn - 4) * ldc4;     // row / mirror row (Rn - 4 - row) byte offsets
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const float a1 = acc1[mt][r], a2 = acc2[mt][r];
+                    if (row < g.rvalid && (!(H2_EXP & 2) || g.batch < 0)) {
+                        if (KIND == 1) {
+                            const f32x2 v2 = {e0 * a1, e3 * a2};
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v2), W0, (int)lo, (int)sk0, 0);
+                        } else {
+                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e0 * a1 + e1 * a2), W0, (int)lo, (int)sk0, 0);
+                            if (row >= 1 && 2 * row != g.Rn)
+                                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(e2 * a1 + e3 * a2), W0, (int)lm, (int)sm0, 0);
+                        }
+                    }
+                    const unsigned st = ((r & 3) == 3) ? 5u * ldc4 : ldc4;
+                    sk0 += st; sm0 -= st;
+                }
+        }
+        if (!more) break;
+        e = en;
+        tile = next;
+    }
+#undef H2_MIXTAB
+#undef H2_FSETUP
+#undef H2_LSETUP
+#undef H2_RSRC
+#undef H2_BLOAD
+#undef H2_BLOAD2
+#undef H2_LOAD
+#undef H2_FOLD
+#undef H2_MAXEXP
+#undef H2_MFMA
+}
+
+}  // namespace
+
+int dft_h2_build_image(const float *A0, const float *A1, int MP, int KP, int lda, unsigned short *img) {
+    std::memset(img, 0, DFT_H2_IMAGE_HALFS * sizeof(unsigned short));
+    float amax = 0.f;
+    const float *A[2] = {A0, A1};
+    for (int m = 0; m < 2; ++m)
+        for (int r = 0; r < MP; ++r)
+            for (int k = 0; k < KP; ++k) amax = std::fmax(amax, std::fabs(A[m][(size_t)r * lda + k]));
+    int pa = 0;
+    if (amax > 0.f) std::frexp(amax, &pa);                       // amax < 2^pa
+    const int kA = 14 - pa;                                       // largest piece below 2^14
+    for (int m = 0; m < 2; ++m)
+        for (int r = 0; r < MP; ++r)
+            for (int k = 0; k < KP; ++k) {
+                const float xs = std::ldexp(A[m][(size_t)r * lda + k], kA);
+                const _Float16 hh = (_Float16)xs;
+                const _Float16 ll = (_Float16)(xs - (float)hh);
+                const int kt = k / BK, c = (k % BK) / 8, j = k % 8;
+                const size_t pos = (size_t)kt * PIECE + (size_t)r * RS + 8 * (c ^ ((r >> 3) & 1)) + j;
+                unsigned short uh, ul;
+                std::memcpy(&uh, &hh, 2);
+                std::memcpy(&ul, &ll, 2);
+                img[((size_t)(m * 2 + 0) * KT) * PIECE + pos] = uh;
+                img[((size_t)(m * 2 + 1) * KT) * PIECE + pos] = ul;
+            }
+    return kA;
+}
+
+int launch_dft_h2(hipStream_t stream, const DftH2Args &g, const unsigned short *img, int kA) {
+    if (g.kind < 0 || g.kind > 2 || g.KP % BK || g.KP < 2 * BK || g.KP > KT * BK || g.N % 128 || g.batch < 1 || !img || !g.src || !g.dst)
+        return (int)hipErrorInvalidValue;
+    if (g.kind != 2 && g.KP > g.Kn) return (int)hipErrorInvalidValue;
+    if (g.rvalid < 1 || g.rvalid > 128) return (int)hipErrorInvalidValue;
+    // 32-bit scalar row offsets (source rows 0 .. Kn, destination rows 0 .. max(Rn, 128) + 4) and 32-bit lane offsets
+    const double rows_src = (double)(g.Kn > g.KP ? g.Kn : g.KP) + 9.0, rows_dst = (double)(g.Rn > 128 ? g.Rn : 128) + 9.0;
+    if (rows_src * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0 || rows_dst * (double)g.ldc * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
+    const int mix_rows = g.Kn > g.KP ? g.Kn : g.KP;
+    if (g.mhat && (g.kind != 0 || g.LP % 128 || g.T < 1 || g.T > 4 || mix_rows > MIX_ROWS || !g.tpl)) return (int)hipErrorInvalidValue;
+    static int cus_of[64] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;
+    if (!cus_of[dev]) {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return (int)hipErrorInvalidDevice;
+        cus_of[dev] = cus;
+    }
+    const int tnw = g.kind == 0 ? 16 : 32;
+    const long NT = (long)(g.N / tnw) * g.batch;
+    const long NS = (NT + NWAVES - 1) / NWAVES;
+    if (NS >= 2147483647L / 8) return (int)hipErrorInvalidValue;
+    dim3 grid((unsigned)(NS < cus_of[dev] ? NS : cus_of[dev]));
+    const uint4 *im = reinterpret_cast<const uint4 *>(img);
+    static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    if (g.mhat) {
+        if (int e = ensure_dynamic_lds(dft_h2_kernel<0, true>, LDS_IMG + LDS_MIX, d3)) return e;
+        hipLaunchKernelGGL((dft_h2_kernel<0, true>), grid, dim3(NTHREADS), LDS_IMG + LDS_MIX, stream, g, im, kA, (int)NS, NT);
+    } else if (g.kind == 0) {
+        if (int e = ensure_dynamic_lds(dft_h2_kernel<0, false>, LDS_IMG, d0)) return e;
+        hipLaunchKernelGGL((dft_h2_kernel<0, false>), grid, dim3(NTHREADS), LDS_IMG, stream, g, im, kA, (int)NS, NT);
+    } else if (g.kind == 1) {
+        if (int e = ensure_dynamic_lds(dft_h2_kernel<1, false>, LDS_IMG, d1)) return e;
+        hipLaunchKernelGGL((dft_h2_kernel<1, false>), grid, dim3(NTHREADS), LDS_IMG, stream, g, im, kA, (int)NS, NT);
+    } else {
+        if (int e = ensure_dynamic_lds(dft_h2_kernel<2, false>, LDS_IMG, d2)) return e;
+        hipLaunchKernelGGL((dft_h2_kernel<2, false>), grid, dim3(NTHREADS), LDS_IMG, stream, g, im, kA, (int)NS, NT);
+    }
+    return (int)hipGetLastError();
+}
+
+bool dft_h2_supported(int Na, int Nb, long NAP, long KBP, long LP) {
+    const double pitch = 2.0 * (double)(NAP > KBP ? NAP : KBP) * (double)LP * 4.0;   // largest row pitch of any pass (bytes, interleaved)
+    const int n = Na > Nb ? Na : Nb, m = Na < Nb ? Na : Nb;
+    return n / 2 + 1 <= 128 && m / 2 + 1 > BK && n <= MIX_ROWS && LP % 128 == 0 && ((double)n + 9.0) * pitch + 1024.0 < 4294967296.0;
+}

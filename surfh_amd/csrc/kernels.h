@@ -11,13 +11,15 @@ constexpr int SURFH_MAX_TEMPLATES = 8;
 // Wavelength is the INNERMOST axis of every large array: spectra are [2 (re,im)][PL][LP] floats,
 // PL = KAP*KBP frequency bins, LP = padded number of owned planes (zero padded); mhat is [T][2][PL].
 // T == 0 (no LMM): mhat has the spectrum layout and the operation is element-wise.
+// ilv = 1: the spectra (sotf, spec, and mhat when T == 0) are interleaved complex [PL][LP][2] instead (plans whose
+// transforms run in dft_h2.hip)
 int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, const float *tpl, float *spec,
-                       int T, long PL, int LP);
+                       int T, long PL, int LP, int ilv = 0);
 int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj,
-                       int T, long PL, int LP, bool f64 = false);
+                       int T, long PL, int LP, bool f64 = false, int ilv = 0);
 
 // hth[(t,t')][k] = sum_l tpl[t,l] tpl[t',l] |sotf[k][l]|^2   (mixing.py:177-203), full T x T stored
-int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP);
+int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP, int ilv = 0);
 // out[t][c][k] = sum_t' hth[t][t'][k] in[t'][c][k]            (mixing.py:102-126 with di = dj = 1)
 int launch_wct_hess_apply(hipStream_t s, const float *hth, const float *in, float *out, int T, long PL);
 

@@ -6,12 +6,34 @@ namespace {
 constexpr int TPB = 256;
 
 // ---------------------------------------------------------------------------------------------
-// spectral mix x OTF   (wavelength innermost: spectra are [2][PL][LP])
+// spectral mix x OTF   (wavelength innermost; spectra are planar [2][PL][LP], or with `ilv` interleaved
+// [PL][LP][2] -- the layout of the plans whose transforms run in dft_h2.hip)
 // ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cld4(const float *__restrict__ a, long PL, long k, int LP, int l4, int ilv, float4 &re, float4 &im) {
+    if (ilv) {
+        const float4 v0 = *reinterpret_cast<const float4 *>(a + (k * LP + l4) * 2);
+        const float4 v1 = *reinterpret_cast<const float4 *>(a + (k * LP + l4) * 2 + 4);
+        re = make_float4(v0.x, v0.z, v1.x, v1.z);
+        im = make_float4(v0.y, v0.w, v1.y, v1.w);
+    } else {
+        re = *reinterpret_cast<const float4 *>(a + k * LP + l4);
+        im = *reinterpret_cast<const float4 *>(a + (PL + k) * LP + l4);
+    }
+}
+__device__ __forceinline__ void cst4(float *__restrict__ a, long PL, long k, int LP, int l4, int ilv, const float4 &re, const float4 &im) {
+    if (ilv) {
+        *reinterpret_cast<float4 *>(a + (k * LP + l4) * 2) = make_float4(re.x, im.x, re.y, im.y);
+        *reinterpret_cast<float4 *>(a + (k * LP + l4) * 2 + 4) = make_float4(re.z, im.z, re.w, im.w);
+    } else {
+        *reinterpret_cast<float4 *>(a + k * LP + l4) = re;
+        *reinterpret_cast<float4 *>(a + (PL + k) * LP + l4) = im;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void specmix_fwd_kernel(const float *__restrict__ mhat,
                                                           const float *__restrict__ sotf,
                                                           const float *__restrict__ tpl, float *__restrict__ spec,
-                                                          int T, long PL, int LP) {
+                                                          int T, long PL, int LP, int ilv) {
     const int l4 = (blockIdx.x * TPB + threadIdx.x) * 4;
     if (l4 >= LP) return;
     const long k = blockIdx.y;
@@ -25,18 +47,16 @@ __global__ __launch_bounds__(TPB) void specmix_fwd_kernel(const float *__restric
             si.x += w.x * mi; si.y += w.y * mi; si.z += w.z * mi; si.w += w.w * mi;
         }
     } else {
-        sr = *reinterpret_cast<const float4 *>(mhat + k * LP + l4);
-        si = *reinterpret_cast<const float4 *>(mhat + (PL + k) * LP + l4);
+        cld4(mhat, PL, k, LP, l4, ilv, sr, si);
     }
-    const float4 hr = *reinterpret_cast<const float4 *>(sotf + k * LP + l4);
-    const float4 hi = *reinterpret_cast<const float4 *>(sotf + (PL + k) * LP + l4);
+    float4 hr, hi;
+    cld4(sotf, PL, k, LP, l4, ilv, hr, hi);
     float4 xr, xi;
     xr.x = hr.x * sr.x - hi.x * si.x; xi.x = hr.x * si.x + hi.x * sr.x;
     xr.y = hr.y * sr.y - hi.y * si.y; xi.y = hr.y * si.y + hi.y * sr.y;
     xr.z = hr.z * sr.z - hi.z * si.z; xi.z = hr.z * si.z + hi.z * sr.z;
     xr.w = hr.w * sr.w - hi.w * si.w; xi.w = hr.w * si.w + hi.w * sr.w;
-    *reinterpret_cast<float4 *>(spec + k * LP + l4) = xr;
-    *reinterpret_cast<float4 *>(spec + (PL + k) * LP + l4) = xi;
+    cst4(spec, PL, k, LP, l4, ilv, xr, xi);
 }
 
 constexpr int MAXT = SURFH_MAX_TEMPLATES;
@@ -46,16 +66,15 @@ template <typename ACC>
 __global__ __launch_bounds__(TPB) void specmix_adj_kernel(const float *__restrict__ spec,
                                                           const float *__restrict__ sotf,
                                                           const float *__restrict__ tpl, float *__restrict__ madj,
-                                                          int T, long PL, int LP) {
+                                                          int T, long PL, int LP, int ilv) {
     const long k = blockIdx.x;
     ACC ar[MAXT], ai[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) ar[t] = ai[t] = (ACC)0;
     for (int l4 = threadIdx.x * 4; l4 < LP; l4 += TPB * 4) {
-        const float4 hr = *reinterpret_cast<const float4 *>(sotf + k * LP + l4);
-        const float4 hi = *reinterpret_cast<const float4 *>(sotf + (PL + k) * LP + l4);
-        const float4 yr = *reinterpret_cast<const float4 *>(spec + k * LP + l4);
-        const float4 yi = *reinterpret_cast<const float4 *>(spec + (PL + k) * LP + l4);
+        float4 hr, hi, yr, yi;
+        cld4(sotf, PL, k, LP, l4, ilv, hr, hi);
+        cld4(spec, PL, k, LP, l4, ilv, yr, yi);
         float4 pr, pi;
         pr.x = hr.x * yr.x + hi.x * yi.x; pi.x = hr.x * yi.x - hi.x * yr.x;
         pr.y = hr.y * yr.y + hi.y * yi.y; pi.y = hr.y * yi.y - hi.y * yr.y;
@@ -95,32 +114,118 @@ __global__ __launch_bounds__(TPB) void specmix_adj_kernel(const float *__restric
 // no-LMM adjoint: out[c][k][l] = (conj(H) Y)[c][k][l]
 __global__ __launch_bounds__(TPB) void specmix_adj_plane_kernel(const float *__restrict__ spec,
                                                                 const float *__restrict__ sotf,
-                                                                float *__restrict__ out, long PL, int LP) {
+                                                                float *__restrict__ out, long PL, int LP, int ilv) {
     const int l4 = (blockIdx.x * TPB + threadIdx.x) * 4;
     if (l4 >= LP) return;
     const long k = blockIdx.y;
-    const float4 hr = *reinterpret_cast<const float4 *>(sotf + k * LP + l4);
-    const float4 hi = *reinterpret_cast<const float4 *>(sotf + (PL + k) * LP + l4);
-    const float4 yr = *reinterpret_cast<const float4 *>(spec + k * LP + l4);
-    const float4 yi = *reinterpret_cast<const float4 *>(spec + (PL + k) * LP + l4);
+    float4 hr, hi, yr, yi;
+    cld4(sotf, PL, k, LP, l4, ilv, hr, hi);
+    cld4(spec, PL, k, LP, l4, ilv, yr, yi);
     float4 pr, pi;
     pr.x = hr.x * yr.x + hi.x * yi.x; pi.x = hr.x * yi.x - hi.x * yr.x;
     pr.y = hr.y * yr.y + hi.y * yi.y; pi.y = hr.y * yi.y - hi.y * yr.y;
     pr.z = hr.z * yr.z + hi.z * yi.z; pi.z = hr.z * yi.z - hi.z * yr.z;
     pr.w = hr.w * yr.w + hi.w * yi.w; pi.w = hr.w * yi.w - hi.w * yr.w;
-    *reinterpret_cast<float4 *>(out + k * LP + l4) = pr;
-    *reinterpret_cast<float4 *>(out + (PL + k) * LP + l4) = pi;
+    cst4(out, PL, k, LP, l4, ilv, pr, pi);
+}
+
+// ---- the same three operations on interleaved spectra [PL][LP][2]: a thread handles two complex values = one
+// float4 of each array, so every wave instruction reads whole contiguous lines -------------------------------------
+__global__ __launch_bounds__(TPB) void specmix_fwd_ilv_kernel(const float *__restrict__ mhat, const float *__restrict__ sotf,
+                                                              const float *__restrict__ tpl, float *__restrict__ spec,
+                                                              int T, long PL, int LP) {
+    const int l2 = (blockIdx.x * TPB + threadIdx.x) * 2;
+    if (l2 >= LP) return;
+    const long k = blockIdx.y;
+    float sr0 = 0.f, si0 = 0.f, sr1 = 0.f, si1 = 0.f;
+    if (T > 0) {
+        for (int t = 0; t < T; ++t) {
+            const float2 w = *reinterpret_cast<const float2 *>(tpl + (long)t * LP + l2);
+            const float mr = mhat[((long)t * 2 + 0) * PL + k];
+            const float mi = mhat[((long)t * 2 + 1) * PL + k];
+            sr0 += w.x * mr; si0 += w.x * mi; sr1 += w.y * mr; si1 += w.y * mi;
+        }
+    } else {
+        const float4 m = *reinterpret_cast<const float4 *>(mhat + (k * LP + l2) * 2);
+        sr0 = m.x; si0 = m.y; sr1 = m.z; si1 = m.w;
+    }
+    const float4 hh = *reinterpret_cast<const float4 *>(sotf + (k * LP + l2) * 2);
+    *reinterpret_cast<float4 *>(spec + (k * LP + l2) * 2) =
+        make_float4(hh.x * sr0 - hh.y * si0, hh.x * si0 + hh.y * sr0, hh.z * sr1 - hh.w * si1, hh.z * si1 + hh.w * sr1);
+}
+
+template <typename ACC>
+__global__ __launch_bounds__(TPB) void specmix_adj_ilv_kernel(const float *__restrict__ spec, const float *__restrict__ sotf,
+                                                              const float *__restrict__ tpl, float *__restrict__ madj,
+                                                              int T, long PL, int LP) {
+    const long k = blockIdx.x;
+    ACC ar[MAXT], ai[MAXT];
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) ar[t] = ai[t] = (ACC)0;
+    const float *hk = sotf + k * LP * 2, *yk = spec + k * LP * 2;
+    for (int l0 = threadIdx.x * 2; l0 < LP; l0 += TPB * 4) {      // two float4 of each array in flight per thread
+        const int l1 = l0 + TPB * 2;
+        const bool two = l1 < LP;
+        const float4 ha = *reinterpret_cast<const float4 *>(hk + (long)l0 * 2);
+        const float4 ya = *reinterpret_cast<const float4 *>(yk + (long)l0 * 2);
+        const float4 hb = two ? *reinterpret_cast<const float4 *>(hk + (long)l1 * 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 yb = two ? *reinterpret_cast<const float4 *>(yk + (long)l1 * 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float pr0 = ha.x * ya.x + ha.y * ya.y, pi0 = ha.x * ya.y - ha.y * ya.x;
+        const float pr1 = ha.z * ya.z + ha.w * ya.w, pi1 = ha.z * ya.w - ha.w * ya.z;
+        const float pr2 = hb.x * yb.x + hb.y * yb.y, pi2 = hb.x * yb.y - hb.y * yb.x;
+        const float pr3 = hb.z * yb.z + hb.w * yb.w, pi3 = hb.z * yb.w - hb.w * yb.z;
+#pragma unroll
+        for (int t = 0; t < MAXT; ++t)
+            if (t < T) {
+                const float2 wa = *reinterpret_cast<const float2 *>(tpl + (long)t * LP + l0);
+                const float2 wb = two ? *reinterpret_cast<const float2 *>(tpl + (long)t * LP + l1) : make_float2(0.f, 0.f);
+                ar[t] += (ACC)wa.x * (ACC)pr0 + (ACC)wa.y * (ACC)pr1 + (ACC)wb.x * (ACC)pr2 + (ACC)wb.y * (ACC)pr3;
+                ai[t] += (ACC)wa.x * (ACC)pi0 + (ACC)wa.y * (ACC)pi1 + (ACC)wb.x * (ACC)pi2 + (ACC)wb.y * (ACC)pi3;
+            }
+    }
+    __shared__ ACC red[TPB / 64][2 * MAXT];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int t = 0; t < MAXT; ++t) {
+        ACC a = ar[t], b = ai[t];
+        for (int o = 32; o > 0; o >>= 1) {
+            a += __shfl_down(a, o, 64);
+            b += __shfl_down(b, o, 64);
+        }
+        if (lane == 0) {
+            red[wv][2 * t] = a;
+            red[wv][2 * t + 1] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * T) {
+        ACC s = (ACC)0;
+        for (int w = 0; w < TPB / 64; ++w) s += red[w][threadIdx.x];
+        const int t = threadIdx.x >> 1, c = threadIdx.x & 1;
+        madj[((long)t * 2 + c) * PL + k] = (float)s;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void specmix_adj_plane_ilv_kernel(const float *__restrict__ spec, const float *__restrict__ sotf,
+                                                                    float *__restrict__ out, long PL, int LP) {
+    const int l2 = (blockIdx.x * TPB + threadIdx.x) * 2;
+    if (l2 >= LP) return;
+    const long k = blockIdx.y;
+    const float4 hh = *reinterpret_cast<const float4 *>(sotf + (k * LP + l2) * 2);
+    const float4 y = *reinterpret_cast<const float4 *>(spec + (k * LP + l2) * 2);
+    *reinterpret_cast<float4 *>(out + (k * LP + l2) * 2) =
+        make_float4(hh.x * y.x + hh.y * y.y, hh.x * y.y - hh.y * y.x, hh.z * y.z + hh.w * y.w, hh.z * y.w - hh.w * y.z);
 }
 
 // one workgroup per frequency bin: the T x T Hessian block sum_l tpl tpl' |H|^2
 __global__ __launch_bounds__(TPB) void wct_hessian_kernel(const float *__restrict__ sotf, const float *__restrict__ tpl,
-                                                          float *__restrict__ hth, int T, long PL, int LP) {
+                                                          float *__restrict__ hth, int T, long PL, int LP, int ilv) {
     const long k = blockIdx.x;
     float acc[MAXT * (MAXT + 1) / 2];
 #pragma unroll
     for (int i = 0; i < MAXT * (MAXT + 1) / 2; ++i) acc[i] = 0.f;
     for (int l = threadIdx.x; l < LP; l += TPB) {
-        const float hr = sotf[k * LP + l], hi = sotf[(PL + k) * LP + l];
+        const float hr = ilv ? sotf[(k * LP + l) * 2] : sotf[k * LP + l], hi = ilv ? sotf[(k * LP + l) * 2 + 1] : sotf[(PL + k) * LP + l];
         const float h2 = hr * hr + hi * hi;
         float w[MAXT];
 #pragma unroll
@@ -880,29 +985,42 @@ constexpr int DOT_BLOCKS = 512;
 }  // namespace
 
 int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, const float *tpl, float *spec, int T,
-                       long PL, int LP) {
+                       long PL, int LP, int ilv) {
     if (T > MAXT) return (int)hipErrorInvalidValue;
+    if (ilv) {
+        dim3 grid((LP / 2 + TPB - 1) / TPB, (unsigned)PL);
+        hipLaunchKernelGGL(specmix_fwd_ilv_kernel, grid, dim3(TPB), 0, s, mhat, sotf, tpl, spec, T, PL, LP);
+        return (int)hipGetLastError();
+    }
     dim3 grid((LP / 4 + TPB - 1) / TPB, (unsigned)PL);
-    hipLaunchKernelGGL(specmix_fwd_kernel, grid, dim3(TPB), 0, s, mhat, sotf, tpl, spec, T, PL, LP);
+    hipLaunchKernelGGL(specmix_fwd_kernel, grid, dim3(TPB), 0, s, mhat, sotf, tpl, spec, T, PL, LP, 0);
     return (int)hipGetLastError();
 }
 
 int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj, int T,
-                       long PL, int LP, bool f64) {
+                       long PL, int LP, bool f64, int ilv) {
     if (T > MAXT) return (int)hipErrorInvalidValue;
+    if (ilv) {
+        if (T == 0) {
+            dim3 grid((LP / 2 + TPB - 1) / TPB, (unsigned)PL);
+            hipLaunchKernelGGL(specmix_adj_plane_ilv_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP);
+        } else if (f64) hipLaunchKernelGGL(specmix_adj_ilv_kernel<double>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
+        else hipLaunchKernelGGL(specmix_adj_ilv_kernel<float>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
+        return (int)hipGetLastError();
+    }
     if (T == 0) {
         dim3 grid((LP / 4 + TPB - 1) / TPB, (unsigned)PL);
-        hipLaunchKernelGGL(specmix_adj_plane_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP);
+        hipLaunchKernelGGL(specmix_adj_plane_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP, 0);
     } else {
-        if (f64) hipLaunchKernelGGL(specmix_adj_kernel<double>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
-        else hipLaunchKernelGGL(specmix_adj_kernel<float>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
+        if (f64) hipLaunchKernelGGL(specmix_adj_kernel<double>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP, 0);
+        else hipLaunchKernelGGL(specmix_adj_kernel<float>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP, 0);
     }
     return (int)hipGetLastError();
 }
 
-int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP) {
+int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP, int ilv) {
     if (T < 1 || T > MAXT) return (int)hipErrorInvalidValue;
-    hipLaunchKernelGGL(wct_hessian_kernel, dim3((unsigned)PL), dim3(TPB), 0, s, sotf, tpl, hth, T, PL, LP);
+    hipLaunchKernelGGL(wct_hessian_kernel, dim3((unsigned)PL), dim3(TPB), 0, s, sotf, tpl, hth, T, PL, LP, ilv);
     return (int)hipGetLastError();
 }
 

@@ -33,6 +33,7 @@
 #include "../../include/surfh_amd.h"
 #include "dft_fold.h"
 #include "dft_rx3.h"
+#include "dft_h2.h"
 #include "gemm_f32.h"
 #include "kernels.h"
 
@@ -160,6 +161,11 @@ struct surfh_plan {
     // gather / scatter rows) -- the strict dot test; storage stays fp32
     bool verify = false;
     int prior_kind = 0;                          // 0: separated first differences (NpDiff_r / NpDiff_c); 1: joint Laplacian (surfh_set_prior)
+    // two-piece fp16 passes with LDS-resident matrices (dft_h2.h): the plan's complex arrays (sotf, spec, ycol, and
+    // mhat when T == 0) are then INTERLEAVED [..][LP][2] instead of planar [2][..][LP]
+    bool h2 = false;
+    unsigned short *h2img = nullptr;             // three images: (Cma, Sma), (Gc, Gs), (Cf, Sf)
+    int h2kA[3] = {0, 0, 0};
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
@@ -804,7 +810,61 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
     return 0;
 }
 
+// ---- two-piece fp16 passes, matrices resident in LDS, interleaved complex arrays (dft_h2.h) --------
+// cube [NBP][NAP][LP] -> spec [KAP][KBP][LP][2]        (tmp ycol viewed as Z[KBP][NAP][LP][2])
+int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst) {
+    const long LP = p->LP;
+    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    DftH2Args g;   // r2c along beta
+    g.kind = 1; g.src = src; g.ldb = p->NAP * LP; g.Kn = p->Nb;
+    g.dst = p->ycol; g.ldc = 2 * p->NAP * LP; g.e[0] = 1.f; g.e[3] = -1.f; g.rvalid = hb;
+    g.KP = p->KPb; g.N = (int)(p->Na * LP);
+    {
+        Prof pr(p, "dft_h2_rows_fwd");
+        LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img + 2 * DFT_H2_IMAGE_HALFS, p->h2kA[2]));
+    }
+    DftH2Args h;   // c2c along alpha, batched over k_beta
+    h.kind = 0; h.src = p->ycol; h.ldb = 2 * LP; h.sB = 2 * p->NAP * LP; h.Kn = p->Na;
+    h.dst = dst; h.ldc = 2 * p->KBP * LP; h.sC = 2 * LP; h.Rn = p->Na; h.rvalid = ha;
+    h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
+    h.e[0] = 1.f; h.e[1] = 1.f; h.e[2] = 1.f; h.e[3] = -1.f;                 // Re Z[r] = C ae + S bo, Re Z[N-r] = C ae - S bo
+    h.e_alt[0] = 1.f; h.e_alt[1] = -1.f; h.e_alt[2] = 1.f; h.e_alt[3] = 1.f;  // Im Z[r] = C be - S ao, Im Z[N-r] = C be + S ao
+    {
+        Prof pr(p, "dft_h2_cols_fwd");
+        LAUNCH_OK(launch_dft_h2(p->stream, h, p->h2img, p->h2kA[0]));
+    }
+    return 0;
+}
+
+// spec [KAP][KBP][LP][2] -> cube [NBP][NAP][LP]        (tmp ycol viewed as Y[NAP][KBP][LP][2])
+int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix) {
+    const long LP = p->LP;
+    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    DftH2Args g;   // c2c along alpha (optionally with the spectral mix formed in the loader)
+    g.kind = 0; g.src = src; g.ldb = 2 * p->KBP * LP; g.Kn = p->Na;
+    g.dst = p->ycol; g.ldc = 2 * p->KBP * LP; g.Rn = p->Na; g.rvalid = ha;
+    g.KP = p->KPa; g.N = (int)(hb * LP);
+    g.e[0] = 1.f; g.e[1] = -1.f; g.e[2] = 1.f; g.e[3] = 1.f;
+    g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = 1.f; g.e_alt[3] = -1.f;
+    if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
+    {
+        Prof pr(p, mix ? "dft_h2_cols_inv_mix" : "dft_h2_cols_inv");
+        LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img, p->h2kA[0]));
+    }
+    DftH2Args h;   // c2r along beta, batched over alpha: cube[b] = Gc Yr - Gs Yi, cube[N-b] = Gc Yr + Gs Yi
+    h.kind = 2; h.src = p->ycol; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
+    h.dst = dst; h.ldc = p->NAP * LP; h.sC = LP;
+    h.e[0] = 1.f; h.e[1] = -1.f; h.e[2] = 1.f; h.e[3] = 1.f; h.Rn = p->Nb; h.rvalid = hb;
+    h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
+    {
+        Prof pr(p, "dft_h2_rows_inv");
+        LAUNCH_OK(launch_dft_h2(p->stream, h, p->h2img + DFT_H2_IMAGE_HALFS, p->h2kA[1]));
+    }
+    return 0;
+}
+
 int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
+    if (p->h2) return rfft2_lam_h2(p, src, dst);
     if (p->rx3) return rfft2_lam_rx3(p, src, dst);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -845,6 +905,7 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
 }
 
 int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = false) {
+    if (p->h2) return irfft2_lam_h2(p, src, dst, mix);
     if (p->rx3) return irfft2_lam_rx3(p, src, dst, mix);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -912,7 +973,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
     } else {
         {
             Prof pr(p, "specmix_fwd");
-            LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP));
+            LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP, p->h2));
         }
         if (irfft2_cube(p, p->spec, p->cube)) return 1;
     }
@@ -1039,7 +1100,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
     if (rfft2_cube(p, acc, p->spec)) return 1;
     {
         Prof pr(p, "specmix_adj");
-        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify));
+        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->h2));
     }
     if (p->T > 0) {
         if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
@@ -1076,7 +1137,7 @@ int ensure_hessian(surfh_plan *p) {
         hipFree(m2);
         return 1;
     }
-    const int rc = launch_wct_hessian(p->stream, p->sotf, p->tpl, h, p->T, p->PL, p->LP);
+    const int rc = launch_wct_hessian(p->stream, p->sotf, p->tpl, h, p->T, p->PL, p->LP, p->h2);
     if (rc != 0) {
         hipFree(h);
         hipFree(m2);
@@ -1112,6 +1173,7 @@ int surfh_plan_destroy(surfh_plan *p) {
                      p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->gcube, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
         hipFree(v);
     hipFree(p->dft3);
+    hipFree(p->h2img);
     hipFree(p->dscal);
     hipFree(p->dscratch);
     hipFree(p->cg_hist);
@@ -1219,8 +1281,14 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     p->isize = (long)(p->T > 0 ? p->T : p->Lc) * p->Na * p->Nb;
     const size_t LP = (size_t)p->LP;
 
+    {   // which transform kernels run decides the layout of the complex arrays: two-piece fp16 passes (default where
+        // the matrices fit LDS) keep them interleaved
+        const char *eh = getenv("SURFH_DFT_H2"), *er = getenv("SURFH_DFT_RX3"), *ed = getenv("SURFH_DFT_DENSE"), *ef = getenv("SURFH_FOLD2");
+        p->h2 = !cfg->verify && !(eh && eh[0] == '0') && !(er && er[0] == '0') && !(ed && ed[0] == '1') && !(ef && ef[0] == '1') &&
+                dft_h2_supported(p->Na, p->Nb, p->NAP, p->KBP, p->LP);
+    }
     // ---- constants ------------------------------------------------------------------------
-    {   // sotf [Lc][Na][Nb/2+1] complex128  ->  [2][KAP][KBP][LP] float, wavelength innermost
+    {   // sotf [Lc][Na][Nb/2+1] complex128  ->  [2][KAP][KBP][LP] float (h2: [KAP][KBP][LP][2]), wavelength innermost
         const int nkb = p->Nb / 2 + 1;
         const size_t nsp = (size_t)2 * p->PL * LP;
         if (dev_alloc(&p->sotf, nsp)) return bail(1);
@@ -1232,10 +1300,21 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                 if (p->planes[l] < 0) continue;     // alignment gap between segments: stays zero
                 const double *src = cfg->sotf ? cfg->sotf + ((size_t)p->planes[l] * p->Na + a) * nkb * 2 : nullptr;
                 for (int k = 0; k < nkb; ++k) {
-                    row[(size_t)k * LP + l] = src ? (float)src[2 * k] : 1.f;
-                    row[((size_t)p->KBP + k) * LP + l] = src ? (float)src[2 * k + 1] : 0.f;
+                    const float vr = src ? (float)src[2 * k] : 1.f, vi = src ? (float)src[2 * k + 1] : 0.f;
+                    if (p->h2) {
+                        row[((size_t)k * LP + l) * 2] = vr;
+                        row[((size_t)k * LP + l) * 2 + 1] = vi;
+                    } else {
+                        row[(size_t)k * LP + l] = vr;
+                        row[((size_t)p->KBP + k) * LP + l] = vi;
+                    }
                 }
             }
+            if (p->h2) {
+                if (hipMemcpy(p->sotf + (size_t)a * p->KBP * LP * 2, row.data(), (size_t)2 * p->KBP * LP * sizeof(float),
+                              hipMemcpyHostToDevice) != hipSuccess)
+                    return bail(fail("sotf upload failed"));
+            } else
             for (int c = 0; c < 2; ++c)
                 if (hipMemcpy(p->sotf + ((size_t)c * p->PL + (size_t)a * p->KBP) * LP, row.data() + (size_t)c * p->KBP * LP,
                               (size_t)p->KBP * LP * sizeof(float), hipMemcpyHostToDevice) != hipSuccess)
@@ -1317,6 +1396,14 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             p->fuse_mix = false;
             p->wblur_fp32 = true;
             p->overlap = false;
+        }
+        if (p->h2) {   // LDS images of the three matrix pairs (dft_h2.h)
+            if (p->MPa != 128 || p->MPb != 128) return bail(fail("internal: dft_h2 needs 128-row folded matrices"));
+            std::vector<unsigned short> im(3 * DFT_H2_IMAGE_HALFS);
+            p->h2kA[0] = dft_h2_build_image(Cma.data(), Sma.data(), p->MPa, p->KPa, p->KPa, im.data());
+            p->h2kA[1] = dft_h2_build_image(Gc.data(), Gs.data(), p->MPb, p->KPb, p->KPb, im.data() + DFT_H2_IMAGE_HALFS);
+            p->h2kA[2] = dft_h2_build_image(Cf.data(), Sf.data(), p->MPb, p->KPb, p->KPb, im.data() + 2 * DFT_H2_IMAGE_HALFS);
+            if (dev_upload(&p->h2img, im)) return bail(1);
         }
         const char *e5 = getenv("SURFH_DFT_RX3");
         p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
@@ -1578,7 +1665,7 @@ int surfh_wct_forward(surfh_plan *p, const float *maps, float *cube) {
     HIP_OK(hipMemcpyAsync(p->io_x, maps, p->isize * sizeof(float), hipMemcpyHostToDevice, s));
     LAUNCH_OK(launch_pad_planes(s, p->io_x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
-    LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP));
+    LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP, p->h2));
     if (irfft2_cube(p, p->spec, p->cube)) return 1;
     LAUNCH_OK(launch_cube_from_lam_inner(s, p->cube, p->io_cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP));
     HIP_OK(hipMemcpyAsync(cube, p->io_cube, (size_t)p->Lc * p->Na * p->Nb * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1594,7 +1681,7 @@ int surfh_wct_adjoint(surfh_plan *p, const float *cube, float *maps) {
     LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
     LAUNCH_OK(launch_cube_to_lam_inner(s, p->io_cube, p->cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP));
     if (rfft2_cube(p, p->cube, p->spec)) return 1;
-    LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP));
+    LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, false, p->h2));
     if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
     LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, p->io_x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     HIP_OK(hipMemcpyAsync(maps, p->io_x, p->isize * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1649,7 +1736,7 @@ int surfh_wct_expsol(surfh_plan *p, const float *cube, const double *mu_reg, con
     if (!rc) rc = launch_cube_to_lam_inner(s, p->io_cube, p->cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP);
     if (rc) return done(fail("launch failed: %s", hipGetErrorString((hipError_t)rc)));
     if (rfft2_cube(p, p->cube, p->spec)) return done(1);
-    rc = launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP);
+    rc = launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, false, p->h2);
     if (!rc) rc = launch_wct_solve(s, p->hth, dreg, dmu, p->mhat, p->mhat2, p->T, p->PL, dflag);
     if (rc) return done(fail("launch failed: %s", hipGetErrorString((hipError_t)rc)));
     if (irfft2_planes(p, p->mhat2, p->maps_pad, p->T)) return done(1);
@@ -2177,8 +2264,10 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
     *ptr = nullptr;
     if (w == "blurred" || w == "gcube") {          // [beta][alpha][lambda]; the exact adjoint's accumulator may be its own buffer
         *ptr = (w == "gcube" && p->gcube) ? p->gcube : p->cube; dims[0] = p->NBP; dims[1] = p->NAP; dims[2] = p->LP;
-    } else if (w == "spec") {                       // [2][k_alpha][k_beta][lambda]
-        *ptr = p->spec; dims[0] = 2; dims[1] = p->KAP; dims[2] = p->KBP; dims[3] = p->LP;
+    } else if (w == "spec") {                       // [2][k_alpha][k_beta][lambda]; h2 plans: [k_alpha][k_beta][lambda][2]
+        *ptr = p->spec;
+        if (p->h2) { dims[0] = p->KAP; dims[1] = p->KBP; dims[2] = p->LP; dims[3] = 2; }
+        else { dims[0] = 2; dims[1] = p->KAP; dims[2] = p->KBP; dims[3] = p->LP; }
     } else if (w == "mhat" && p->T > 0) {
         *ptr = p->mhat; dims[0] = p->T; dims[1] = 2; dims[2] = p->KAP; dims[3] = p->KBP;
     } else if (w.rfind("xs:", 0) == 0 || w.rfind("xsinfo:", 0) == 0) {

@@ -460,12 +460,13 @@ def test_disjoint_wavelength_windows(lmm):
 
 @pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_RX3": "0", "SURFH_FOLD2": "1"},
                                  {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
-                                 {"SURFH_WBLUR_PC": "0"}, {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_PACKED": "0"},
+                                 {"SURFH_WBLUR_PC": "0"}, {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_H2": "0", "SURFH_DFT_PACKED": "0"},
+                                 {"SURFH_DFT_H2": "0"},
                                  {"SURFH_WBLUR_F16": "0"}, {"SURFH_WBLUR_F16": "0", "SURFH_WBLUR_PRESPLIT": "0"},
                                  {"SURFH_GATHER_SORTED": "0"}, {"SURFH_SCATTER_RMW_ALL": "1"}, {"SURFH_WBLUR_CC": "0"},
                                  {"SURFH_WBLUR_CC": "1"}, {"SURFH_SCATTER_GROUPED": "0"}, {"SURFH_GATHER_GROUPED": "0"}],
                          ids=["fold_fp32", "fold_fp32_two_launch", "dense_dft", "unfused_mix", "wblur_fp32", "wblur_4wave",
-                              "two_streams", "dft_two_pass_complex", "wblur_bf16_three_piece", "wblur_bf16_split_in_kernel",
+                              "two_streams", "dft_bf16_two_pass_complex", "dft_bf16_three_piece", "wblur_bf16_three_piece", "wblur_bf16_split_in_kernel",
                               "gather_rows_unsorted", "scatter_rmw_everywhere", "wblur_producer_consumer", "wblur_cc_adjoint_only",
                               "scatter_row_by_row", "gather_row_by_row"])
 def test_alternative_kernel_paths(env):
