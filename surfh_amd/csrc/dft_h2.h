@@ -48,6 +48,7 @@ struct DftH2Args {
     const float *mhat = nullptr, *tpl = nullptr;   // optional fused spectral mix (kind 0)
     int T = 0, LP = 0;
     long PL = 0, KBP = 0;
+    int mix_l0 = 0;                            // with batch > 1 (a wavelength chunk, batched over kb): first plane of the chunk
 };
 
 // host: builds the LDS image of the two row-major [MP][KP] fp32 matrices (MP <= 128, KP <= 128, KP % 16 == 0);

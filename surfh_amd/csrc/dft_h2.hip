@@ -28,7 +28,10 @@ constexpr int IMG_HALFS = (int)DFT_H2_IMAGE_HALFS;    // 65536 halfs = 128 KB
 constexpr int MIX_ROWS = 256;                         // rows of one spectral-mix table ([k][re/im] float4): 8 KB
 constexpr size_t LDS_IMG = (size_t)IMG_HALFS * 2;
 constexpr size_t LDS_MIX = (size_t)2 * MIX_ROWS * 2 * sizeof(float4);
-constexpr int NTHREADS = 512, NWAVES = 8;
+#ifndef H2_WAVES
+#define H2_WAVES 8
+#endif
+constexpr int NWAVES = H2_WAVES, NTHREADS = 64 * NWAVES;
 constexpr int E_TARGET = 10, E_LIMIT = 15;            // a column's largest scaled magnitude: set below 2^10, rescaled at 2^15
 
 #define MFMA3(acc_, ah_, al_, bh_, bl_)                                             \
@@ -81,7 +84,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
     // this workgroup's contiguous range of super-tiles (8 wave tiles each); wave w takes tile 8 s + w
     const int s0 = (int)((long)NS * blockIdx.x / gridDim.x), s1 = (int)((long)NS * (blockIdx.x + 1) / gridDim.x);
     int ntw = s1 - s0;
-    if (ntw > 0 && (long)8 * (s1 - 1) + wave >= NT) --ntw;
+    if (ntw > 0 && (long)NWAVES * (s1 - 1) + wave >= NT) --ntw;
 
     // fused spectral mix: the (k, kb) column of mhat, all k, as [k][re/im] x 4 templates in LDS, one table per kb parity
     const float4 *mtab = mixbuf;
@@ -107,7 +110,9 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
 #define H2_FSETUP(t_)                                                                                           \
     if (MIX) {                                                                                                  \
         const int fn0 = ((t_) % tilesX) * TNW;                                                                   \
-        const int kb = fn0 / g.LP, l = (fn0 % g.LP) + lcol;                                                     \
+        /* whole-cube launch: column n = kb LP + l; wavelength-chunk launch (batch > 1): batch entry = kb */     \
+        const int kb = g.batch > 1 ? (t_) / tilesX : fn0 / g.LP;                                                \
+        const int l = g.mix_l0 + (g.batch > 1 ? fn0 : fn0 % g.LP) + lcol;                                       \
         float t4[4];                                                                                            \
         _Pragma("unroll") for (int t = 0; t < 4; ++t) t4[t] = (t < g.T) ? g.tpl[(long)t * g.LP + l] : 0.f;      \
         tw = make_float4(t4[0], t4[1], t4[2], t4[3]);                                                           \
@@ -208,7 +213,8 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
 
     if (MIX) {                         // first table (the barrier also publishes the matrix image)
         if (ntw > 0) {
-            const int kb0 = (((8 * s0 + wave) % tilesX) * TNW) / g.LP;
+            const int t0_ = NWAVES * s0 + wave;
+            const int kb0 = g.batch > 1 ? t0_ / tilesX : ((t0_ % tilesX) * TNW) / g.LP;
             H2_MIXTAB(kb0);
         }
     }
@@ -219,7 +225,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
     // step's raw values, loads of the step after that, the first stream's fragments rebuilt in place, MFMAs of the
     // second matrix, the second stream's fragments rebuilt.  At a tile seam the next tile's first two k-steps are
     // requested before the stores of the epilogue.
-    int tile = 8 * s0 + wave;
+    int tile = NWAVES * s0 + wave;
     const int tend = tile + NWAVES * ntw;              // this wave's tiles: tile, tile + 8, ... < tend
     int e = 0, en = 0;                                  // block exponents of the current / next k-step's column
 
@@ -381,7 +387,7 @@ int launch_dft_h2(hipStream_t stream, const DftH2Args &g, const unsigned short *
     const int tnw = g.kind == 0 ? 16 : 32;
     const long NT = (long)(g.N / tnw) * g.batch;
     const long NS = (NT + NWAVES - 1) / NWAVES;
-    if (NS >= 2147483647L / 8) return (int)hipErrorInvalidValue;
+    if (NS >= 2147483647L / NWAVES) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(NS < cus_of[dev] ? NS : cus_of[dev]));
     const uint4 *im = reinterpret_cast<const uint4 *>(img);
     static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;

@@ -154,5 +154,68 @@ int main(int argc, char **argv) {
             printf("%-16s h2 vs rx3: rel L2 %.3e   max|d| %.3e (max|ref| %.3e)\n", name, std::sqrt(hacc[0] / hacc[1]), hacc[2], hacc[3]);
         }
     }
+    // ---- the forward transform (mix + c2c along alpha, then c2r along beta) whole-cube against wavelength chunks whose
+    // half-transformed intermediate is a small reused buffer (Infinity-Cache resident), chunks alternating on two streams
+    {
+        hipStream_t st2[2]; CK(hipStreamCreate(&st2[0])); CK(hipStreamCreate(&st2[1]));
+        hipLaunchKernelGGL(ilv_k, dim3(2048), dim3(256), 0, st, spec, spec + plane, ilv, plane);
+        CK(hipStreamSynchronize(st));
+        auto whole = [&](float *cube_out) {
+            DftH2Args q; q.KP = KP;
+            q.kind = 0; q.src = ilv; q.ldb = 2 * KBP * LP; q.Kn = Na; q.dst = outI; q.ldc = 2 * KBP * LP; q.Rn = Na; q.rvalid = ha; q.N = (int)(hb * LP);
+            q.e[0] = 1; q.e[1] = -1; q.e[2] = 1; q.e[3] = 1; q.e_alt[0] = 1; q.e_alt[1] = 1; q.e_alt[2] = 1; q.e_alt[3] = -1;
+            q.mhat = mhat; q.tpl = tpl; q.T = 4; q.LP = (int)LP; q.PL = (long)NAP * KBP; q.KBP = KBP;
+            launch_dft_h2(st, q, img, kA);
+            DftH2Args r; r.KP = KP;
+            r.kind = 2; r.src = outI; r.ldb = 2 * LP; r.sB = 2 * KBP * LP; r.dst = cube_out; r.ldc = NAP * LP; r.sC = LP;
+            r.e[0] = 1; r.e[1] = -1; r.e[2] = 1; r.e[3] = 1; r.Rn = Nb; r.rvalid = hb; r.N = (int)LP; r.batch = Na;
+            launch_dft_h2(st, r, img, kA);
+        };
+        for (int i = 0; i < 2; ++i) whole(outA);
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 10; ++i) whole(outA);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("forward transform whole cube          %.4f ms\n", ms / 10);
+        for (long LPc : {256L, 512L, 1024L}) {
+            if (LPc > LP) continue;
+            float *yb[2];
+            CK(hipMalloc(&yb[0], (size_t)2 * NAP * KBP * LPc * 4)); CK(hipMalloc(&yb[1], (size_t)2 * NAP * KBP * LPc * 4));
+            for (int nstream = 1; nstream <= 2; ++nstream) {
+                auto chunked = [&](float *cube_out) {
+                    for (long c = 0; c * LPc < LP; ++c) {
+                        hipStream_t s_ = st2[nstream == 2 ? (c & 1) : 0];
+                        float *y = yb[nstream == 2 ? (c & 1) : 0];
+                        const long l0 = c * LPc;
+                        DftH2Args q; q.KP = KP;
+                        q.kind = 0; q.src = ilv + 2 * l0; q.ldb = 2 * KBP * LP; q.sB = 2 * LP; q.batch = hb; q.Kn = Na;
+                        q.dst = y; q.ldc = 2 * KBP * LPc; q.sC = 2 * LPc; q.Rn = Na; q.rvalid = ha; q.N = (int)LPc;
+                        q.e[0] = 1; q.e[1] = -1; q.e[2] = 1; q.e[3] = 1; q.e_alt[0] = 1; q.e_alt[1] = 1; q.e_alt[2] = 1; q.e_alt[3] = -1;
+                        q.mhat = mhat; q.tpl = tpl; q.T = 4; q.LP = (int)LP; q.PL = (long)NAP * KBP; q.KBP = KBP; q.mix_l0 = (int)l0;
+                        launch_dft_h2(s_, q, img, kA);
+                        DftH2Args r; r.KP = KP;
+                        r.kind = 2; r.src = y; r.ldb = 2 * LPc; r.sB = 2 * KBP * LPc; r.dst = cube_out + l0; r.ldc = NAP * LP; r.sC = LP;
+                        r.e[0] = 1; r.e[1] = -1; r.e[2] = 1; r.e[3] = 1; r.Rn = Nb; r.rvalid = hb; r.N = (int)LPc; r.batch = Na;
+                        launch_dft_h2(s_, r, img, kA);
+                    }
+                };
+                for (int i = 0; i < 2; ++i) chunked(outB);
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, st2[0]));
+                for (int i = 0; i < 10; ++i) chunked(outB);
+                CK(hipStreamSynchronize(st2[1]));
+                CK(hipEventRecord(e1, st2[0])); CK(hipEventSynchronize(e1));
+                CK(hipEventElapsedTime(&ms, e0, e1));
+                CK(hipMemsetAsync(acc, 0, 32, st));
+                hipLaunchKernelGGL(diff_k, dim3(1024), dim3(256), 0, st, outB, outA, (long)ncube, acc);
+                double hacc[4];
+                CK(hipMemcpyAsync(hacc, acc, 32, hipMemcpyDeviceToHost, st));
+                CK(hipStreamSynchronize(st));
+                printf("forward transform chunks of %4ld, %d stream(s)  %.4f ms   (vs whole: rel L2 %.3e)\n", LPc, nstream, ms / 10, std::sqrt(hacc[0] / hacc[1]));
+            }
+            CK(hipFree(yb[0])); CK(hipFree(yb[1]));
+        }
+    }
     return 0;
 }
