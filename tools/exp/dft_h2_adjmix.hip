@@ -1,3 +1,6 @@
+// EXPERIMENT (parked, round 2): dft_h2.hip + a fused adjoint tail `dft_h2_adjmix_kernel` (complex pass along alpha whose epilogue
+// forms conj(H) Y and reduces it over the wavelengths) -- correct (2e-7 against a float64 reference) but 0.90 ms against 0.84 ms
+// for the pass + specmix_adj_ilv_kernel it would replace: see tools/exp/README.md.
 // Two-piece fp16 DFT pass with LDS-resident matrices, decoupled waves and interleaved complex arrays (see dft_h2.h).
 // One persistent workgroup of eight waves per CU; a wave owns all 128 output rows of its 32 lane-columns (32 real
 // columns, or 16 complex columns x 2 components), i.e. 2 products x 4 row tiles x 16 = 128 accumulator registers,
@@ -5,8 +8,8 @@
 // (the fused spectral mix adds one per change of k_beta).  Each wave pipelines its stream of k-steps: raw loads two
 // steps ahead, fold / scale / split one step ahead, MFMAs on the current step; a tile's stores are issued after its
 // last MFMA group, behind loads that are already in flight.
-#include "dft_h2.h"
-#include "lds_attr.h"
+#include "dft_h2_adjmix.h"
+#include "../../surfh_amd/csrc/lds_attr.h"
 #include <cmath>
 #include <cstring>
 
@@ -328,6 +331,294 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Adjoint tail, fused: the complex pass along alpha of rfft2 (kind 0) whose epilogue, instead of storing the spectrum
+// Y[ka][kb][l], forms conj(H) Y and reduces it over the wavelengths with the template weights -- the reference's
+// `sum_l tpl[t,l] conj(sotf) rfft2(cube)` (spectroModel.py:175-181) -- so the 1 GB spectrum is neither written nor read
+// back and `specmix_adj_kernel` disappears.
+//
+// The MFMA operands swap roles: the data fragments go in as A, the matrix fragments as B.  The fragment registers are the
+// same, but the accumulator then has lane = output row (k_alpha) and registers = the tile's 32 lane-columns, i.e. a
+// register quad is (re, im) of two adjacent wavelengths of ONE row: the product with conj(H) needs no cross-lane move and
+// the sum over wavelengths runs inside the lane.  A lane carries sum_l tpl[t][l] z[l] for its rows (4 templates x re/im x
+// (row r, row N-r) per row tile) across all tiles of one k_beta: that is 16 registers per row tile, so the eight waves
+// split the work as 4 column streams x 2 row halves (waves w and w + 4 transform the same columns, each for 64 of the 128
+// output rows; the second read of a tile comes from L1 / L2).  The block exponent is per tile (wave-uniform) here, because
+// an accumulator register no longer belongs to the lane that folded its column.
+// Partial sums leave the kernel once per (workgroup, k_beta) into `mpart[kb][slot][row][t][c]`; a second, tiny kernel adds
+// the slots in a fixed order (deterministic, no atomics).
+__device__ __forceinline__ float wave_max(float m) {
+#define H2_DPPMAX(ctrl_) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), ctrl_, 0xF, 0xF, false)))
+    H2_DPPMAX(0xB1);     // quad_perm [1,0,3,2]
+    H2_DPPMAX(0x4E);     // quad_perm [2,3,0,1]
+    H2_DPPMAX(0x141);    // row_half_mirror
+    H2_DPPMAX(0x140);    // row_mirror: every lane of a row of 16 holds the row's maximum
+#undef H2_DPPMAX
+    unsigned u = __float_as_uint(m);
+    auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    m = fmaxf(m, fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1])));
+    u = __float_as_uint(m);
+    auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(m, fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1])));
+}
+
+__global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, DftH2AdjMix am, const uint4 *__restrict__ img, int kA, int NS) {
+    static_assert(NWAVES == 8, "dft_h2_adjmix_kernel: 4 column streams x 2 row halves");
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    constexpr int KIND = 0;
+    constexpr bool MIX = false;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cs = wave & 3, rh = wave >> 2;                   // column stream, row half
+    const int l31 = lane & 31, h = lane >> 5;
+    constexpr int TNW = 16, SRC_T = 32;
+    const int lcol = l31 >> 1;
+    const int tilesX = g.N / TNW;
+    const unsigned ldb4 = (unsigned)(g.ldb * 4), ldh4 = (unsigned)(am.ldh * 4);
+    const unsigned c4 = (unsigned)l31 * 4u;
+    const int nk = g.KP / BK;
+    const int kin = g.Kn / 2 + 1;
+    // unused by this kernel, referenced by the shared macros
+    const float4 *mtab = nullptr;
+    const float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float sgv = 0.f;
+    (void)mtab; (void)tw; (void)sgv; (void)lcol;
+    {
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < IMG_HALFS / 8; i += NTHREADS) l4[i] = img[i];
+    }
+    // super-tiles of 4 tiles (64 complex columns); wave (cs, rh) takes tile 4 s + cs
+    const int s0 = (int)((long)NS * blockIdx.x / gridDim.x), s1 = (int)((long)NS * (blockIdx.x + 1) / gridDim.x);
+    const int ntw = s1 - s0;
+    __syncthreads();
+    if (ntw <= 0) return;
+
+    __amdgpu_buffer_rsrc_t R0;
+    int hv = h;
+    float xr[8], qr[8];
+    float x0[8], x1[8];
+    f16x8 c0h, c0l, c1h, c1l;
+    f32x16 acc1[2], acc2[2];
+    f32x2 M[2][2][4];                  // [row tile][row r / row N - r][template] (re, im)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) M[i][k][t] = f32x2{0.f, 0.f};
+
+    // fragments of the matrix rows of this wave's half: B operand now (same registers as the A fragment of dft_h2_kernel)
+#define H2_MFMA_SW(m_, kt_, acc_, bh_, bl_)                                                                     \
+    {                                                                                                           \
+        const unsigned short *ra = lds + ((m_) * 2 * KT + (kt_)) * PIECE + (rh * 64 + l31) * RS + 8 * (h ^ ((l31 >> 3) & 1)); \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                      \
+            const unsigned short *p = ra + mt * 32 * RS;                                                        \
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(p);                                               \
+            const f16x8 al = *reinterpret_cast<const f16x8 *>(p + KT * PIECE);                                  \
+            f32x16 c_ = acc_[mt];                                                                               \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_, ah, c_, 0, 0, 0);                                  \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, al, c_, 0, 0, 0);                                  \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, ah, c_, 0, 0, 0);                                  \
+            acc_[mt] = c_;                                                                                      \
+        }                                                                                                       \
+    }
+    // exponent of the tile's largest folded magnitude (wave-uniform)
+#define H2_MAXEXP_W(p_)                                                                                         \
+    {                                                                                                           \
+        float m_ = 0.f;                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) m_ = fmaxf(m_, fmaxf(fabsf(x0[j]), fabsf(x1[j])));        \
+        m_ = wave_max(m_);                                                                                      \
+        p_ = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(m_));                                   \
+    }
+    // partial sums of one k_beta leave the wave: the two lane halves (different wavelengths of the same rows) are added,
+    // lanes 0-31 store [row][t][c]
+#define H2_FLUSH(kb_)                                                                                           \
+    {                                                                                                           \
+        const long spk = tilesX / 4;                   /* super-tiles per k_beta */                              \
+        int bf = (int)blockIdx.x;                                                                               \
+        while (bf > 0 && (long)NS * bf / gridDim.x > (long)(kb_) * spk) --bf;     /* first workgroup that holds tiles of kb */ \
+        const int slot = ((int)blockIdx.x - bf) * 4 + cs;                                                       \
+        float *mp = am.mpart + ((long)(kb_) * am.nslot + slot) * (256 * 8);                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+            _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                     \
+                float v[8];                                                                                     \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
+                    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                             \
+                        const unsigned u = __float_as_uint(M[i][k][t][c]);                                      \
+                        const auto sw_ = __builtin_amdgcn_permlane32_swap(u, u, false, false);                  \
+                        v[2 * t + c] = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);   /* lower half + upper half, in every lane */ \
+                    }                                                                                           \
+                    M[i][k][t] = f32x2{0.f, 0.f};                                                               \
+                }                                                                                               \
+                const int r = (2 * rh + i) * 32 + l31;                                                          \
+                const int row = k ? g.Rn - r : r;                                                               \
+                const bool ok_ = k ? (r >= 1 && r < g.rvalid && 2 * r != g.Rn) : (r < g.rvalid);                \
+                if (h == 0 && slot < am.nslot && ok_) {                                                         \
+                    *reinterpret_cast<float4 *>(mp + row * 8) = make_float4(v[0], v[1], v[2], v[3]);            \
+                    *reinterpret_cast<float4 *>(mp + row * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);        \
+                }                                                                                               \
+            }                                                                                                   \
+    }
+
+    int tile = 4 * s0 + cs;
+    const int tend = tile + 4 * ntw;
+    int e = 0, en = 0;
+
+    H2_LSETUP(tile);
+    H2_LOAD(0);
+    H2_FOLD(0);
+    {
+        int p;
+        H2_MAXEXP_W(p);
+        e = E_TARGET - p;
+    }
+    split8h(x0, e, c0h, c0l);
+    split8h(x1, e, c1h, c1l);
+    H2_LOAD(1);
+    while (true) {
+        asm volatile("" : "+v"(hv));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
+        const int next = tile + 4;
+        const bool more = next < tend;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            H2_MFMA_SW(0, kt, acc1, c0h, c0l);
+            H2_FOLD(kt + 1);
+            int p;
+            H2_MAXEXP_W(p);
+            en = (p + e > E_LIMIT) ? E_TARGET - p : e;
+            const int d = en - e;
+            if (kt + 2 < nk) {
+                H2_LOAD(kt + 2);
+            } else if (more) {
+                H2_LSETUP(next);
+                H2_LOAD(0);
+            }
+            split8h(x0, en, c0h, c0l);
+            H2_MFMA_SW(1, kt, acc2, c1h, c1l);
+            split8h(x1, en, c1h, c1l);
+            if (d != 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc1[mt][r] = __builtin_amdgcn_ldexpf(acc1[mt][r], d);
+                        acc2[mt][r] = __builtin_amdgcn_ldexpf(acc2[mt][r], d);
+                    }
+            }
+            e = en;
+        }
+        // the tile's OTF rows are requested ahead of their use: row tile 0 before the last MFMA groups, row tile 1 before
+        // the arithmetic of row tile 0
+        const int kb = tile / tilesX;
+        const long n0 = (long)(tile % tilesX) * TNW;
+        const __amdgpu_buffer_rsrc_t HR = H2_RSRC(am.hsrc + (long)kb * am.sH + n0 * 2);
+        const unsigned vr = (unsigned)l31 * ldh4 + (unsigned)h * 16u, vm = (unsigned)(31 - l31) * ldh4 + (unsigned)h * 16u;
+        float4 hq[2][4], hm[2][4];
+#define H2_HLOAD(i_)                                                                                            \
+    {                                                                                                           \
+        const int mt = 2 * rh + (i_);                                                                           \
+        const unsigned sr = (unsigned)(mt * 32) * ldh4, sm = (unsigned)(g.Rn - mt * 32 - 31) * ldh4;            \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+            if (H2_EXP & 16) { hq[i_][q] = make_float4(1.f, 0.5f, 0.25f, 2.f); hm[i_][q] = hq[i_][q]; continue; } \
+            hq[i_][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(HR, (int)vr, (int)(sr + 32u * q), 0)); \
+            hm[i_][q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(HR, (int)vm, (int)(sm + 32u * q), 0)); \
+        }                                                                                                       \
+    }
+        H2_MFMA_SW(0, nk - 1, acc1, c0h, c0l);
+        if (more) {
+            H2_FOLD(0);
+            int p;
+            H2_MAXEXP_W(p);
+            en = E_TARGET - p;
+            H2_LOAD(1);
+            split8h(x0, en, c0h, c0l);
+        }
+        H2_HLOAD(0);
+        H2_MFMA_SW(1, nk - 1, acc2, c1h, c1l);
+        if (more) split8h(x1, en, c1h, c1l);
+        {
+            // epilogue: z = conj(H) Y for this lane's rows, summed over the tile's wavelengths with the template weights
+            // the tile's template weights: lane L of `tv` holds tpl[t = L & 3][column L >> 2]; read back lane by lane (scalar)
+            const float tv = ((lane & 3) < am.T) ? am.tpl[(long)(lane & 3) * am.LPt + n0 + (lane >> 2)] : 0.f;
+            const float f = __builtin_amdgcn_ldexpf(1.f, -e - kA);
+            const float e0 = f * g.e[0], e1 = f * g.e[1], e2 = f * g.e[2], e3 = f * g.e[3];
+            const float a0 = f * g.e_alt[0], a1 = f * g.e_alt[1], a2 = f * g.e_alt[2], a3 = f * g.e_alt[3];
+            H2_HLOAD(1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float ta[4], tb[4];      // template weights of this lane's two wavelengths of the quad: columns 4 q + 2 h, + 1
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const float lo0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q) * 4 + t));
+                        const float lo1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q + 1) * 4 + t));
+                        const float hi0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q + 2) * 4 + t));
+                        const float hi1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q + 3) * 4 + t));
+                        ta[t] = h ? hi0 : lo0;
+                        tb[t] = h ? hi1 : lo1;
+                    }
+                    const float p0 = acc1[i][4 * q], p1 = acc1[i][4 * q + 1], p2 = acc1[i][4 * q + 2], p3 = acc1[i][4 * q + 3];
+                    const float s0v = acc2[i][4 * q], s1v = acc2[i][4 * q + 1], s2v = acc2[i][4 * q + 2], s3v = acc2[i][4 * q + 3];
+                    // row r: two wavelengths (yr, yi), then z = conj(H) y
+                    {
+                        const float yr0 = e0 * p0 + e1 * s0v, yi0 = a0 * p1 + a1 * s1v, yr1 = e0 * p2 + e1 * s2v, yi1 = a0 * p3 + a1 * s3v;
+                        const float4 hh = hq[i][q];
+                        const f32x2 z0 = {hh.x * yr0 + hh.y * yi0, hh.x * yi0 - hh.y * yr0};
+                        const f32x2 z1 = {hh.z * yr1 + hh.w * yi1, hh.z * yi1 - hh.w * yr1};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) M[i][0][t] += ta[t] * z0 + tb[t] * z1;
+                    }
+                    // row N - r
+                    {
+                        const float yr0 = e2 * p0 + e3 * s0v, yi0 = a2 * p1 + a3 * s1v, yr1 = e2 * p2 + e3 * s2v, yi1 = a2 * p3 + a3 * s3v;
+                        const float4 hh = hm[i][q];
+                        const f32x2 z0 = {hh.x * yr0 + hh.y * yi0, hh.x * yi0 - hh.y * yr0};
+                        const f32x2 z1 = {hh.z * yr1 + hh.w * yi1, hh.z * yi1 - hh.w * yr1};
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) M[i][1][t] += ta[t] * z0 + tb[t] * z1;
+                    }
+                }
+            }
+        }
+#undef H2_HLOAD
+        if (!more || next / tilesX != kb) H2_FLUSH(kb);
+        if (!more) break;
+        e = en;
+        tile = next;
+    }
+#undef H2_MFMA_SW
+#undef H2_MAXEXP_W
+#undef H2_FLUSH
+}
+
+// madj[t][c][ka * KBP + kb] = sum over the slots that hold partial sums of kb (fixed order)
+__global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *__restrict__ mpart, float *__restrict__ madj, int nslot,
+                                                                   int T, int Na, int hb, long KBP, long PL, int NS, int G, int spk) {
+    const int kb = blockIdx.x;
+    int bf = 0, bl = G - 1;      // workgroups bf .. bl of the pass hold tiles of kb: range of workgroup b = [NS b / G, NS (b + 1) / G)
+    {
+        const long lo = (long)kb * spk, hi = lo + spk;
+        int b = (int)(((long)lo * G) / NS);
+        while (b > 0 && (long)NS * b / G > lo) --b;
+        while ((long)NS * (b + 1) / G <= lo) ++b;
+        bf = b;
+        while (b + 1 < G && (long)NS * (b + 1) / G < hi) ++b;
+        bl = b;
+    }
+    const int ns = (bl - bf + 1) * 4 < nslot ? (bl - bf + 1) * 4 : nslot;
+    for (int i = threadIdx.x; i < Na * 8; i += 256) {
+        const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
+        if (t >= T) continue;
+        float s = 0.f;
+        for (int sl = 0; sl < ns; ++sl) s += mpart[((long)kb * nslot + sl) * (256 * 8) + row * 8 + tc];
+        madj[((long)t * 2 + c) * PL + (long)row * KBP + kb] = s;
+    }
+}
+
 #undef H2_MIXTAB
 #undef H2_FSETUP
 #undef H2_LSETUP
@@ -406,6 +697,46 @@ int launch_dft_h2(hipStream_t stream, const DftH2Args &g, const unsigned short *
         if (int e = ensure_dynamic_lds(dft_h2_kernel<2, false>, LDS_IMG, d2)) return e;
         hipLaunchKernelGGL((dft_h2_kernel<2, false>), grid, dim3(NTHREADS), LDS_IMG, stream, g, im, kA, (int)NS, NT);
     }
+    return (int)hipGetLastError();
+}
+
+// workgroups of the fused adjoint pass and partial-sum slots per k_beta for `tiles_per_kb` = LP / 16 tiles per k_beta
+static void adjmix_geometry(int dev_cus, long tilesX, int hb, long &NS, int &G, int &nslot) {
+    NS = tilesX / 4 * hb;
+    G = (int)(NS < dev_cus ? NS : dev_cus);
+    const long spk = tilesX / 4;
+    const long per = NS / G;                                   // smallest range of a workgroup (super-tiles)
+    nslot = (int)(4 * ((spk + per - 1) / per + 2));
+}
+
+size_t dft_h2_adjmix_part_floats(long LP, int hb) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
+    long NS; int G, nslot;
+    adjmix_geometry(cus, LP / 16, hb, NS, G, nslot);
+    return (size_t)hb * nslot * 256 * 8;
+}
+
+int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjMix &am0, float *madj, long PL, long KBP, const unsigned short *img, int kA) {
+    if (g.kind != 0 || g.mhat || g.KP % BK || g.KP < 2 * BK || g.KP > KT * BK || g.KP > g.Kn || g.N % 128 || g.batch < 1 || !img || !g.src ||
+        !am0.hsrc || !am0.tpl || !am0.mpart || !madj || am0.T < 1 || am0.T > 4 || g.Rn < 32 * 3 + 31 || g.Rn > 255 || g.rvalid < 1 || g.rvalid > 128)
+        return (int)hipErrorInvalidValue;
+    const double rows_src = (double)g.Kn + 9.0;
+    if (rows_src * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0 || 260.0 * (double)am0.ldh * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return (int)hipErrorInvalidDevice;
+    long NS; int G, nslot;
+    adjmix_geometry(cus, g.N / 16, g.batch, NS, G, nslot);
+    if (NS >= 2147483647L / 4) return (int)hipErrorInvalidValue;
+    DftH2AdjMix am = am0;
+    am.nslot = nslot;
+    static unsigned long long d4 = 0;
+    const size_t ldsb = LDS_IMG;
+    if (int e = ensure_dynamic_lds(dft_h2_adjmix_kernel, ldsb, d4)) return e;
+    hipLaunchKernelGGL(dft_h2_adjmix_kernel, dim3((unsigned)G), dim3(NTHREADS), ldsb, stream, g, am, reinterpret_cast<const uint4 *>(img), kA, (int)NS);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dft_h2_adjmix_reduce_kernel, dim3((unsigned)g.batch), dim3(256), 0, stream, am.mpart, madj, nslot, am.T, g.Rn, g.batch, KBP, PL,
+                       (int)NS, G, (int)(g.N / 16 / 4));
     return (int)hipGetLastError();
 }
 

@@ -9,7 +9,11 @@
 #include <cmath>
 #include <vector>
 #include "../../surfh_amd/csrc/dft_rx3.h"
+#ifdef WITH_ADJMIX
+#include "dft_h2_adjmix.h"
+#else
 #include "../../surfh_amd/csrc/dft_h2.h"
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void fill_k(float *p, long n, unsigned seed, int mode, long pitch) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -25,6 +29,25 @@ __global__ void ilv_k(const float *re, const float *im, float *out, long n) {   
 }
 __global__ void dilv_k(const float *in, float *re, float *im, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { re[i] = in[2 * i]; im[i] = in[2 * i + 1]; }
+}
+// reference of the fused adjoint tail: madj[t][c][ka][kb] = sum_l tpl[t][l] (conj(H) Y)[c], float64 accumulation
+__global__ void adjmix_ref_k(const float *Y, const float *H, const float *tpl, float *madj, int T, long LP, long KBP, long PL) {
+    const long k = blockIdx.x;     // ka * KBP + kb
+    double ar[4] = {0, 0, 0, 0}, ai[4] = {0, 0, 0, 0};
+    for (long l = threadIdx.x; l < LP; l += 256) {
+        const double yr = Y[(k * LP + l) * 2], yi = Y[(k * LP + l) * 2 + 1], hr = H[(k * LP + l) * 2], hi = H[(k * LP + l) * 2 + 1];
+        const double zr = hr * yr + hi * yi, zi = hr * yi - hi * yr;
+        for (int t = 0; t < T; ++t) { ar[t] += tpl[t * LP + l] * zr; ai[t] += tpl[t * LP + l] * zi; }
+    }
+    __shared__ double red[256];
+    for (int t = 0; t < T; ++t)
+        for (int c = 0; c < 2; ++c) {
+            red[threadIdx.x] = c ? ai[t] : ar[t];
+            __syncthreads();
+            for (int o = 128; o > 0; o >>= 1) { if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o]; __syncthreads(); }
+            if (threadIdx.x == 0) madj[((long)t * 2 + c) * PL + k] = (float)red[0];
+            __syncthreads();
+        }
 }
 __global__ void diff_k(const float *a, const float *b, long n, double *acc) {   // acc: sum (a-b)^2, sum b^2, max |a-b|, max |b|
     double s0 = 0, s1 = 0, m0 = 0, m1 = 0;
@@ -217,5 +240,40 @@ int main(int argc, char **argv) {
             CK(hipFree(yb[0])); CK(hipFree(yb[1]));
         }
     }
+#ifdef WITH_ADJMIX
+    // ---- fused adjoint tail: complex pass along alpha + conj(H) + wavelength reduction against pass + float64 reference
+    {
+        const long PL = (long)NAP * KBP;
+        float *Hi, *madjA, *madjB, *mpart;
+        CK(hipMalloc(&Hi, nsp * 4)); CK(hipMalloc(&madjA, (size_t)8 * PL * 4)); CK(hipMalloc(&madjB, (size_t)8 * PL * 4));
+        const size_t npart = dft_h2_adjmix_part_floats(LP, hb);
+        CK(hipMalloc(&mpart, npart * 4));
+        printf("adjmix partial buffer: %.1f MB\n", npart * 4 / 1e6);
+        hipLaunchKernelGGL(ilv_k, dim3(2048), dim3(256), 0, st, ycol, ycol + plane, ilv, plane);      // Z[kb][a][l][2]
+        hipLaunchKernelGGL(ilv_k, dim3(2048), dim3(256), 0, st, spec, spec + plane, Hi, plane);        // H[ka][kb][l][2]
+        CK(hipMemsetAsync(madjA, 0, (size_t)8 * PL * 4, st)); CK(hipMemsetAsync(madjB, 0, (size_t)8 * PL * 4, st));
+        DftH2Args q; q.KP = KP;
+        q.kind = 0; q.src = ilv; q.ldb = 2 * LP; q.sB = 2 * NAP * LP; q.Kn = Na; q.dst = outI; q.ldc = 2 * KBP * LP; q.sC = 2 * LP;
+        q.Rn = Na; q.rvalid = ha; q.N = (int)LP; q.batch = hb;
+        q.e[0] = 1; q.e[1] = 1; q.e[2] = 1; q.e[3] = -1; q.e_alt[0] = 1; q.e_alt[1] = -1; q.e_alt[2] = 1; q.e_alt[3] = 1;
+        CK(hipMemsetAsync(outI, 0, nsp * 4, st));
+        if (int rc = launch_dft_h2(st, q, img, kA)) { printf("launch rc %d\n", rc); return 1; }
+        hipLaunchKernelGGL(adjmix_ref_k, dim3((unsigned)PL), dim3(256), 0, st, outI, Hi, tpl, madjA, 4, LP, (long)KBP, PL);
+        DftH2AdjMix am; am.hsrc = Hi; am.ldh = 2 * KBP * LP; am.sH = 2 * LP; am.tpl = tpl; am.T = 4; am.LPt = (int)LP; am.mpart = mpart;
+        for (int i = 0; i < 3; ++i) if (int rc = launch_dft_h2_adjmix(st, q, am, madjB, PL, KBP, img, kA)) { printf("adjmix launch rc %d\n", rc); return 1; }
+        CK(hipStreamSynchronize(st));
+        CK(hipEventRecord(e0, st));
+        for (int i = 0; i < 20; ++i) launch_dft_h2_adjmix(st, q, am, madjB, PL, KBP, img, kA);
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemsetAsync(acc, 0, 32, st));
+        hipLaunchKernelGGL(diff_k, dim3(1024), dim3(256), 0, st, madjB, madjA, (long)8 * PL, acc);
+        double hacc[4];
+        CK(hipMemcpyAsync(hacc, acc, 32, hipMemcpyDeviceToHost, st));
+        CK(hipStreamSynchronize(st));
+        printf("fused adjoint tail (pass + conj(H) + sum over l)  %.4f ms   vs float64 reference: rel L2 %.3e max|d| %.3e (max|ref| %.3e)\n",
+               ms / 20, std::sqrt(hacc[0] / hacc[1]), hacc[2], hacc[3]);
+    }
+#endif
     return 0;
 }
