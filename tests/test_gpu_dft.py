@@ -1,0 +1,119 @@
+"""The 2-D transforms of the hot path against numpy's float64 FFT, through the Fourier-domain model
+``Model_WCT`` (forward = irfft2(sotf * rfft2(sum_t spec[t,l] maps[t])), reference
+surfh/Models/mixing.py:102-270; kernels: surfh/ToolsDir/jax_utils.py:30-41 dft / idft).
+
+Sizes on both sides of the limits of the two-piece fp16 passes (dft_h2.hip: 16 < N/2+1 <= 128, matrices
+resident in LDS, interleaved complex arrays) and of the split-bf16 fallback (dft_rx3.hip, planar
+arrays), even and odd lengths, rectangular images; inputs built to stress the per-column block
+exponent of the fp16 split (hot pixels, spectra spanning 30 decades, rows that grow towards the
+centre so that the accumulators are rescaled k-step after k-step).  Tolerances are fp32-level.
+"""
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 3e-6      # relative L2, fp32 storage + fp32 accumulation (gate of the path: 1e-5)
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.asarray(a, dtype=np.float64) - b) / np.linalg.norm(b))
+
+
+def np_forward(sotf, specs, maps):
+    cube_in = np.einsum("tl,tab->lab", specs, maps)
+    return np.fft.irfft2(sotf * np.fft.rfft2(cube_in), s=maps.shape[-2:])
+
+
+def np_adjoint(sotf, specs, cube):
+    z = np.fft.irfft2(np.conj(sotf) * np.fft.rfft2(cube), s=cube.shape[-2:])
+    return np.einsum("tl,lab->tab", specs, z)
+
+
+def build(shape, L, T, rng, psf_sigma=None):
+    from surfh_amd.mixing import Model_WCT
+    from surfh_amd.synth import ir2fr
+    hs, ws = min(15, shape[0]), min(13, shape[1])
+    yy, xx = np.mgrid[0:hs, 0:ws]
+    if psf_sigma is None:
+        psf_sigma = np.linspace(1.0, 3.0, L)
+    psf_sigma = np.broadcast_to(np.asarray(psf_sigma, dtype=np.float64), (L,))
+    psfs = np.exp(-((yy - hs // 2) ** 2 + (xx - ws // 2) ** 2)[None] / (2.0 * psf_sigma[:, None, None] ** 2))
+    psfs = psfs * (1.0 + 0.1 * rng.standard_normal(psfs.shape))          # not symmetric: a complex OTF
+    psfs /= psfs.sum(axis=(1, 2), keepdims=True)
+    specs = rng.random((T, L)) + 0.1
+    pce = 0.5 + rng.random(L)
+    m = Model_WCT(psfs, specs, shape, pce)
+    sotf = ir2fr(psfs * pce[:, None, None], shape)
+    return m, sotf, specs
+
+
+@pytest.mark.parametrize("shape", [(48, 48), (64, 64), (100, 100), (33, 254), (255, 40), (96, 130), (131, 77), (251, 251), (256, 256), (300, 64)])
+def test_transforms_vs_numpy(shape):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    L, T = 130, 3
+    m, sotf, specs = build(shape, L, T, rng)
+    maps = rng.random((T,) + shape)
+    cube = rng.standard_normal((L,) + shape)
+    ef = rel(m.forward(maps), np_forward(sotf, specs, maps))
+    ea = rel(m.adjoint(cube), np_adjoint(sotf, specs, cube))
+    m.close()
+    print(f"transforms {shape}: forward {ef:.2e} adjoint {ea:.2e}")
+    assert ef < TOL and ea < TOL, (shape, ef, ea)
+
+
+@pytest.mark.parametrize("shape", [(64, 64), (251, 251), (120, 200)])
+def test_block_exponent_dynamic_range(shape):
+    """Hot pixels 1e7 above the background, OTFs from almost flat to a Gaussian that falls by 30 decades, planes whose
+    levels differ by 1e12 inside one wave tile."""
+    rng = np.random.default_rng(5)
+    L, T = 64, 4
+    m, sotf, specs = build(shape, L, T, rng, psf_sigma=np.geomspace(0.4, 6.0, L))
+    specs = specs * np.where(np.arange(L) % 3 == 0, 1e6, 1e-6)[None, :]       # neighbouring planes 1e12 apart
+    m.close()
+    from surfh_amd.mixing import Model_WCT
+    from surfh_amd.synth import ir2fr
+    # rebuild with the scaled spectra (the plan keeps its own copy)
+    hs, ws = min(15, shape[0]), min(13, shape[1])
+    yy, xx = np.mgrid[0:hs, 0:ws]
+    sig = np.geomspace(0.4, 6.0, L)
+    psfs = np.exp(-((yy - hs // 2) ** 2 + (xx - ws // 2) ** 2)[None] / (2.0 * sig[:, None, None] ** 2))
+    psfs /= psfs.sum(axis=(1, 2), keepdims=True)
+    pce = np.ones(L)
+    m = Model_WCT(psfs, specs, shape, pce)
+    sotf = ir2fr(psfs, shape)
+    maps = rng.random((T,) + shape) * 1e-3
+    maps[0, shape[0] // 2, shape[1] // 3] = 1e4
+    maps[2, 3, shape[1] - 2] = 3e3
+    y = m.forward(maps)
+    yr = np_forward(sotf, specs, maps)
+    ef = rel(y, yr)
+    # plane by plane: no plane may lose its precision to a brighter neighbour
+    pe = np.array([np.linalg.norm(y[l] - yr[l]) / np.linalg.norm(yr[l]) for l in range(L)])
+    cube = rng.standard_normal((L,) + shape) * np.where(np.arange(L) % 5 == 0, 1e5, 1e-4)[:, None, None]
+    cube[7, shape[0] // 2, shape[1] // 2] = 1e9
+    ea = rel(m.adjoint(cube), np_adjoint(sotf, specs, cube))
+    m.close()
+    print(f"dynamic range {shape}: forward {ef:.2e} (worst plane {pe.max():.2e}) adjoint {ea:.2e}")
+    assert ef < TOL and pe.max() < 1e-5 and ea < TOL, (ef, pe.max(), ea)
+
+
+@pytest.mark.parametrize("shape", [(251, 251), (128, 64)])
+def test_rows_growing_towards_the_centre(shape):
+    """The folded passes walk a column from both ends inwards: magnitudes that double every few rows towards the centre
+    force the running block exponent down (and the accumulators to be rescaled) at almost every k-step."""
+    rng = np.random.default_rng(11)
+    L, T = 32, 2
+    m, sotf, specs = build(shape, L, T, rng, psf_sigma=1.5)
+    ra = np.minimum(np.arange(shape[0]), shape[0] - np.arange(shape[0]))
+    rb = np.minimum(np.arange(shape[1]), shape[1] - np.arange(shape[1]))
+    grow = np.exp2(ra[:, None] / 4.0 + rb[None, :] / 4.0)                   # up to 2^62 at 251 x 251
+    cube = rng.standard_normal((L,) + shape) * grow[None]
+    ea = rel(m.adjoint(cube), np_adjoint(sotf, specs, cube))
+    maps = rng.random((T,) + shape) * grow[None]
+    ef = rel(m.forward(maps), np_forward(sotf, specs, maps))
+    m.close()
+    print(f"growing rows {shape}: forward {ef:.2e} adjoint {ea:.2e}")
+    assert ef < TOL and ea < TOL, (ef, ea)
