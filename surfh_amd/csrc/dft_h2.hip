@@ -86,7 +86,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
     int ntw = s1 - s0;
     if (ntw > 0 && (long)NWAVES * (s1 - 1) + wave >= NT) --ntw;
 
-    // fused spectral mix: the (k, kb) column of mhat, all k, as [k][re/im] x 4 templates in LDS, one table per kb parity
+    // fused spectral mix: the (k, kb) column of mhat, all k, as [k][template](re, im) in LDS, one table per kb parity
     const float4 *mtab = mixbuf;
     float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
     int mix_kb = -1;
@@ -95,10 +95,12 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
         float4 *mt_ = mixbuf + ((kb_) & 1) * (MIX_ROWS * 2);                                                     \
         const int ne = (g.Kn > g.KP ? g.Kn : g.KP) * 2;                                                         \
         for (int e_ = tid; e_ < ne; e_ += NTHREADS) {                                                           \
-            const int k = e_ >> 1, c = e_ & 1;                                                                  \
+            const int k = e_ >> 1, tp = e_ & 1;        /* float4 = (re, im) of templates 2 tp and 2 tp + 1 */   \
             float v[4];                                                                                         \
-            _Pragma("unroll") for (int t = 0; t < 4; ++t)                                                       \
-                v[t] = (t < g.T && k < g.Kn) ? g.mhat[((long)t * 2 + c) * g.PL + (long)k * g.KBP + (kb_)] : 0.f; \
+            _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                     \
+                const int t = 2 * tp + (i >> 1), c = i & 1;                                                     \
+                v[i] = (t < g.T && k < g.Kn) ? g.mhat[((long)t * 2 + c) * g.PL + (long)k * g.KBP + (kb_)] : 0.f; \
+            }                                                                                                   \
             mt_[e_] = make_float4(v[0], v[1], v[2], v[3]);                                                      \
         }                                                                                                       \
         mtab = mt_;                                                                                             \
@@ -168,13 +170,12 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
                 if (MIX) {      /* own component of (re + i im) * s: re' = re sr - im si, im' = im sr + re si */   \
                     const float ap = pair_swap(a), bp = pair_swap(b);                                           \
                     const int kp = pv ? g.Kn - k : k;                                                           \
-                    const float4 mr = mtab[2 * k], mi = mtab[2 * k + 1], nr = mtab[2 * kp], ni = mtab[2 * kp + 1]; \
-                    const float sr = tw.x * mr.x + tw.y * mr.y + tw.z * mr.z + tw.w * mr.w;                     \
-                    const float si = tw.x * mi.x + tw.y * mi.y + tw.z * mi.z + tw.w * mi.w;                     \
-                    const float ur = tw.x * nr.x + tw.y * nr.y + tw.z * nr.z + tw.w * nr.w;                     \
-                    const float ui = tw.x * ni.x + tw.y * ni.y + tw.z * ni.z + tw.w * ni.w;                     \
-                    a = a * sr + sgv * (ap * si);                                                               \
-                    b = b * ur + sgv * (bp * ui);                                                               \
+                    /* s = sum_t tw[t] (re, im)[t] as packed pairs: two v_pk_fma_f32 per table float4 */             \
+                    const float4 m01 = mtab[2 * k], m23 = mtab[2 * k + 1], n01 = mtab[2 * kp], n23 = mtab[2 * kp + 1]; \
+                    const f32x2 sv = tw.x * f32x2{m01.x, m01.y} + tw.y * f32x2{m01.z, m01.w} + tw.z * f32x2{m23.x, m23.y} + tw.w * f32x2{m23.z, m23.w}; \
+                    const f32x2 uv = tw.x * f32x2{n01.x, n01.y} + tw.y * f32x2{n01.z, n01.w} + tw.z * f32x2{n23.x, n23.y} + tw.w * f32x2{n23.z, n23.w}; \
+                    a = a * sv[0] + sgv * (ap * sv[1]);                                                         \
+                    b = b * uv[0] + sgv * (bp * uv[1]);                                                         \
                 }                                                                                               \
                 const float ev = a + (pv ? b : 0.f), od = pv ? a - b : 0.f;                                     \
                 x0[j] = ev;                                                                                     \
