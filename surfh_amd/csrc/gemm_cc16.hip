@@ -3,8 +3,10 @@
 // operand delivery (48 KB per K step = 60 B/clk per CU, the width of the L1 fill path).  Here one workgroup = 8 waves = one
 // 256 x 256 tile (wave tile 64 x 128, 4 x 2 waves): 64 KB of operands per K step for twice the flops, delivered by LDS-DMA
 // (global_load_lds, no registers, no VALU) into the same XOR-swizzled [piece][row][32 k] image, two 64 KB stages.
+// Results are the same bits as the first (compiler-scheduled) version of this kernel: same products, same order.
 #include "gemm_f32.h"
 #include "lds_attr.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -44,8 +46,159 @@ __global__ __launch_bounds__(256) void split_rows2h_kernel(const float *__restri
     *reinterpret_cast<f16x4 *>(dst + plane + o) = l;
 }
 
+// The kernel's K loop is hand-scheduled.  hipcc puts s_waitcnt lgkmcnt(0) behind every group of LDS reads and vmcnt(0) in
+// front of LDS accesses while a DMA is in flight; scheduled that way (the first version of this file) the LDS latency was
+// exposed five times per K step and the DMA issue of all eight waves stalled in front of their MFMAs: delivery and matrix-core
+// time ADDED (0.123 + 0.142 ms of a 0.267 ms launch at the config-3 forward shape).  Here the fragment reads, the DMA pieces,
+// the MFMAs and their waits are volatile inline assembly in a fixed interleaved order (LDS reads return in order; vmcnt is
+// one in-order counter): on constant operands the loop runs at the matrix cores' rate (0.157 ms, 1.5 PFLOP/s issued); on
+// random operands the chip lowers its clock under the bit toggling and the launch takes 0.24 ms (tools/exp/cc_main.hip).
+// Register budget: 128 accumulators + 64 fragment registers -- the DMA sources are one 32-bit lane offset per 128-row group
+// on scalar bases and the block scales of A sit in LDS (K segments of this slab x 256 rows).
+#ifndef CC_EXP
+#define CC_EXP 0          // experiment mask (tools/exp): 1 no DMA inside the loop, 2 no fragment reads, 4 no MFMAs
+#endif
+constexpr int CC2_MAXSEG = 16;                                        // K segments one slab may cross (launcher checks)
+constexpr size_t LDS2_BYTES = LDS_BYTES + (size_t)CC2_MAXSEG * BM * sizeof(float);
+
+// a pointer the compiler keeps in scalar registers (wave-uniform by construction)
+__device__ __forceinline__ const char *cc2_uniform(const char *p) {
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char *)(((unsigned long long)hi << 32) | lo);
+}
+// segment of column k of the block-scaled A and the k at which it ends; k is wave-uniform, the results are scalars
+__device__ __forceinline__ int cc2_seg_of(int k, int segLinP, int segChunks) {
+    const int col = k / segLinP, in = k % segLinP;
+    return __builtin_amdgcn_readfirstlane(col * segChunks + in / 1024);
+}
+__device__ __forceinline__ int cc2_seg_end(int k, int segLinP) {
+    const int col = k / segLinP, in = k % segLinP;
+    const int e1 = col * segLinP + (in / 1024 + 1) * 1024, e2 = (col + 1) * segLinP;
+    return __builtin_amdgcn_readfirstlane(e1 < e2 ? e1 : e2);
+}
+// old / new for two power-of-two scales (f16x2_scale_of), exact; exponent difference clamped to the normal range
+__device__ __forceinline__ float cc2_pow2_ratio(float so, float sn) {
+    int e = (int)(__float_as_uint(so) >> 23) - (int)(__float_as_uint(sn) >> 23) + 127;
+    e = e < 1 ? 1 : (e > 254 ? 254 : e);
+    return __uint_as_float((unsigned)e << 23);
+}
+// 1 KiB of one piece (16 rows x 64 B) from global memory straight into LDS at byte address `l` (wave-uniform)
+__device__ __forceinline__ void cc2_dma(const char *base, unsigned off, unsigned l) {
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory");
+}
+
+// The instruction stream of one K step is four units of 12 MFMAs: unit U = (half step hs = U >> 1, column-block pair
+// jp = U & 1) multiplies the A fragments of its half step (row blocks i = 0, 1) with the B fragments of column blocks
+// j = 2 jp, 2 jp + 1 -- products l*h, h*l, h*h per block, the order of the first kernel.  Behind MFMA n of a unit, so that
+// they issue in the shadow of the matrix cores and of the SIMD's other wave: n < 4 the B fragment reads of the NEXT unit,
+// 4 <= n < 8 (RDA) the A fragment reads of the next half step, and (DMA) eight DMA pieces of a later stage in slots
+// 1, 2, 4, 5, 7, 8, 10, 11.  Everything is volatile assembly: the compiler keeps the order and adds no waits of its own.
+template <int U, int N, bool RDB, bool RDA, bool DMA>
+__device__ __forceinline__ void cc2_slot(f32x16 (&acc)[2][4], const f16x8 (&Ac)[2][2], const f16x8 (&Bc)[2][2], f16x8 (&An)[2][2],
+                                         f16x8 (&Bn)[2][2], unsigned ran, unsigned rbn, const char *ka, const char *kb, long pA2, long pB2,
+                                         const unsigned (&offA)[2], const unsigned (&offB)[2], unsigned ls) {
+    constexpr int jp = U & 1, jj = N / 6, j = 2 * jp + jj, i = (N / 3) & 1, p = N % 3;
+    if constexpr (!(CC_EXP & 4))
+        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(Ac[i][p == 0 ? 1 : 0]), "v"(Bc[jj][p == 1 ? 1 : 0]));
+    constexpr int R = N;                           // read slot
+    if constexpr (RDB && R < 4 && !(CC_EXP & 2)) {
+        constexpr int jn = 2 * ((U + 1) & 1) + (R >> 1), q = R & 1;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Bn[R >> 1][q]) : "v"(rbn), "n"(q * PIECE * 2 + jn * 32 * BK * 2));
+    }
+    if constexpr (RDA && R >= 4 && R < 8 && !(CC_EXP & 2)) {
+        constexpr int in = (R - 4) >> 1, q = R & 1;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(An[in][q]) : "v"(ran), "n"(q * PIECE * 2 + in * 32 * BK * 2));
+    }
+    constexpr int d = (N % 3 != 0) ? N - 1 - N / 3 : -1;       // pieces 0..7 behind MFMAs 1, 2, 4, 5, 7, 8, 10, 11
+    if constexpr (DMA && d >= 0 && !(CC_EXP & 1)) {
+        constexpr int q = d >> 2, i2 = (d >> 1) & 1;
+        if constexpr (d & 1) cc2_dma(kb + q * pB2, offB[i2], ls + (unsigned)((q * PIECE + (BM + i2 * 128) * BK) * 2));
+        else cc2_dma(ka + q * pA2, offA[i2], ls + (unsigned)((q * PIECE + i2 * 128 * BK) * 2));
+    }
+}
+template <int U, bool RDB, bool RDA, bool DMA, int N = 0>
+__device__ __forceinline__ void cc2_unit(f32x16 (&acc)[2][4], const f16x8 (&Ac)[2][2], const f16x8 (&Bc)[2][2], f16x8 (&An)[2][2],
+                                         f16x8 (&Bn)[2][2], unsigned ran, unsigned rbn, const char *ka, const char *kb, long pA2, long pB2,
+                                         const unsigned (&offA)[2], const unsigned (&offB)[2], unsigned ls) {
+    if constexpr (N < 12) {
+        cc2_slot<U, N, RDB, RDA, DMA>(acc, Ac, Bc, An, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
+        cc2_unit<U, RDB, RDA, DMA, N + 1>(acc, Ac, Bc, An, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
+    }
+}
+
+// wait for every LDS read of this wave; the registers are operands so that no use of them can be moved in front of it
+#define CC_WAIT(A_, B_)                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                 : "+v"(A_[0][0]), "+v"(A_[1][0]), "+v"(A_[0][1]), "+v"(A_[1][1]), "+v"(B_[0][0]), "+v"(B_[1][0]), "+v"(B_[0][1]), "+v"(B_[1][1]))
+// the accumulators are written by assembly MFMAs the compiler knows nothing about: before ordinary code reads them, let the
+// last one drain (a 32x32x16 MFMA takes 8 passes of 4 cycles)
+#define CC_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory")
+
+struct Cc2Loop {           // wave-uniform state of the main loop
+    const char *baseA, *baseB;
+    long pA2, pB2;
+    unsigned ldsw;
+    int nk, kbeg;
+    const float *sctab;    // nullptr: one scale per row (amax), no rescaling inside the loop
+    int seg0, seg, seg_end, segLinP, segChunks;
+};
+
+// main loop of a wave; on entry the fragments of unit 0 of stage 0 are in Ae / Bx
+__device__ __forceinline__ void cc2_mainloop(f32x16 (&acc)[2][4], f16x8 (&Ae)[2][2], f16x8 (&Ao)[2][2], f16x8 (&Bx)[2][2], f16x8 (&By)[2][2],
+                                             unsigned ra0, unsigned ra1, unsigned rb0, unsigned rb1, const unsigned (&offA)[2],
+                                             const unsigned (&offB)[2], int srow, Cc2Loop &L) {
+    for (int kt = 0; kt < L.nk; ++kt) {
+        if (L.sctab && L.kbeg + kt * BK >= L.seg_end) {     // workgroup-uniform, once per <= 1024 k
+            const int k = L.kbeg + kt * BK;
+            const int nseg = cc2_seg_of(k, L.segLinP, L.segChunks);
+            L.seg_end = cc2_seg_end(k, L.segLinP);
+            CC_MFMA_DRAIN();
+            const float *to = L.sctab + (L.seg - L.seg0) * BM + srow, *tn_ = L.sctab + (nseg - L.seg0) * BM + srow;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const float4 so = *reinterpret_cast<const float4 *>(to + i * 32 + 8 * r4);
+                    const float4 sn4 = *reinterpret_cast<const float4 *>(tn_ + i * 32 + 8 * r4);
+                    const float ra[4] = {cc2_pow2_ratio(so.x, sn4.x), cc2_pow2_ratio(so.y, sn4.y), cc2_pow2_ratio(so.z, sn4.z),
+                                         cc2_pow2_ratio(so.w, sn4.w)};
+#pragma unroll
+                    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[i][j][4 * r4 + rr] *= ra[rr];
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            L.seg = nseg;
+        }
+        // DMA of K step kt + 2 -> stage kt & 1, issued in unit 3.  One instruction stream for every kt: in the last two steps
+        // the DMA repeats the last K step into a stage nobody reads any more and the reads fetch fragments nobody uses.
+        const int k2 = kt + 2 < L.nk ? kt + 2 : L.nk - 1;
+        const char *ka2 = L.baseA + (long)k2 * (BK * 2), *kb2 = L.baseB + (long)k2 * (BK * 2);
+        const unsigned ls2 = L.ldsw + (unsigned)(kt & 1) * (STAGE * 2);
+        // unit 0 (k 0..15, columns 0..63): reads B of unit 1
+        cc2_unit<0, true, false, false>(acc, Ae, Bx, Ao, By, ra1, rb0, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
+        CC_WAIT(Ae, By);
+        // unit 1 (k 0..15, columns 64..127): reads B of unit 2 and A of the second half step
+        cc2_unit<1, true, true, false>(acc, Ae, By, Ao, Bx, ra1, rb1, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
+        CC_WAIT(Ao, Bx);
+        // unit 2 (k 16..31, columns 0..63): reads B of unit 3, the last fragments of this stage
+        cc2_unit<2, true, false, false>(acc, Ao, Bx, Ae, By, ra0, rb1, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
+        CC_WAIT(Ao, By);
+        // K step kt + 1 landed (this wave's DMAs are all older); every wave holds the last fragments of stage kt & 1 in registers
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        ra0 ^= STAGE * 2; ra1 ^= STAGE * 2; rb0 ^= STAGE * 2; rb1 ^= STAGE * 2;
+        // unit 3 (k 16..31, columns 64..127): reads A and B of the next K step's unit 0 from the other stage
+        cc2_unit<3, true, true, true>(acc, Ao, By, Ae, Bx, ra0, rb0, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
+        CC_WAIT(Ae, Bx);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus DMAs must land before the LDS is given back
+    CC_MFMA_DRAIN();
+}
+
 __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    float *sctab = reinterpret_cast<float *>(lds + 2 * STAGE);       // [segment - seg0][row of the tile]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN, tiles = tilesM * tilesN;
     const long total = (long)tiles * g.splitK * g.batch, per = (total + 7) / 8;
@@ -57,36 +210,37 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int Kper = g.K / g.splitK, kbeg = sk * Kper, nk = Kper / BK;
 
-    // DMA: one wave instruction moves 64 x 16 B = 16 rows of one piece (row = lane >> 2, LDS chunk = lane & 3, which holds
-    // the global 16-byte chunk (lane & 3) ^ ((row >> 2) & 3) of that row).  A stage has 2 pieces x 512 rows = 64 such
-    // groups; wave w moves groups w, w + 8, ... (8 per K step).
-    const unsigned short *gsrc[8];
-    int gdst[8];
+    // DMA: one wave instruction moves 16 rows x 64 B of one piece (row = lane >> 2; LDS chunk lane & 3 holds the global
+    // chunk (lane & 3) ^ (lane >> 4 & 3) of the row).  Wave w moves the 16-row groups w, w + 8 (A rows), w + 16, w + 24
+    // (B rows) of both pieces: four lane offsets (bytes) on scalar bases.
+    unsigned offA[2], offB[2];
+    {
+        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int grp = wave + 8 * i;              // 0..63: piece = grp >> 5, 16-row group inside the piece = grp & 31
-        const int q = grp >> 5, row = (grp & 31) * 16 + (lane >> 2);
-        const int chunk = (lane & 3) ^ ((row >> 2) & 3);
-        const unsigned short *base;
-        if (row < BM) {
-            int m = m0 + row;
-            m = m < g.M ? m : g.M - 1;             // ragged last tile: clamp, the rows are not stored
-            base = g.A3 + (long)b * g.sA + q * g.pA3 + (long)m * g.lda;
-        } else {
-            int n = n0 + row - BM;
+        for (int i = 0; i < 2; ++i) {
+            int m = m0 + (wave + 8 * i) * 16 + (lane >> 2);
+            m = m < g.M ? m : g.M - 1;                 // ragged last tile: clamp, the rows are not stored
+            offA[i] = (unsigned)(((long)m * g.lda + 8 * chunk) * 2);
+            int n = n0 + (wave + 8 * i) * 16 + (lane >> 2);
             n = n < g.N ? n : g.N - 1;
-            base = g.B16 + (long)b * g.sB + q * g.pB16 + (long)n * g.ldb;
+            offB[i] = (unsigned)(((long)n * g.ldb + 8 * chunk) * 2);
         }
-        gsrc[i] = base + kbeg + 8 * chunk;
-        gdst[i] = q * PIECE + (grp & 31) * 16 * BK;            // wave-uniform LDS base of the group (lane-linear behind it)
     }
-#define CC_DMA(kt_, st_)                                                                                             \
-    {                                                                                                                \
-        _Pragma("unroll") for (int i = 0; i < 8; ++i)                                                                \
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc[i] + (kt_) * BK),  \
-                                             (__attribute__((address_space(3))) void *)(lds + (st_) * STAGE + gdst[i]), 16, 0, 0); \
+    const char *baseA = cc2_uniform(reinterpret_cast<const char *>(g.A3 + (long)b * g.sA + kbeg));
+    const char *baseB = cc2_uniform(reinterpret_cast<const char *>(g.B16 + (long)b * g.sB + kbeg));
+    const long pA2 = g.pA3 * 2, pB2 = g.pB16 * 2;
+    const unsigned ldsw = (unsigned)(size_t)lds + (unsigned)(wave * 16 * BK * 2);     // byte address of the wave's first group
+#define CC_DMA(kt_, st_)                                                                                               \
+    {                                                                                                                  \
+        const char *ka = baseA + (long)(kt_) * (BK * 2), *kb = baseB + (long)(kt_) * (BK * 2);                         \
+        const unsigned ls = ldsw + (unsigned)(st_) * (STAGE * 2);                                                      \
+        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                                \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
+                cc2_dma(ka + q * pA2, offA[i], ls + (q * PIECE + i * 128 * BK) * 2);                                   \
+                cc2_dma(kb + q * pB2, offB[i], ls + (q * PIECE + (BM + i * 128) * BK) * 2);                            \
+            }                                                                                                          \
+        }                                                                                                              \
     }
-
     const int l31 = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves, wave tile 64 x 128
     f32x16 acc[2][4];
@@ -97,90 +251,78 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     const int sw = (l31 >> 2) & 3;
-    const int fa = (wm * 64 + l31) * BK;
-    const int fb = (BM + wn * 128 + l31) * BK;
-
-    // ragged last row tile: the waves whose 64 rows lie beyond M only move data.  Waves w and w + 4 share a SIMD and differ
-    // by two 64-row blocks, so a half-empty tile costs half the matrix-core time.
+    // fragment byte addresses of the two half steps in stage 0: chunk (2 * s2 + h) ^ sw of the lane's row; the stage is
+    // toggled by XOR with its size
+    unsigned ra0 = (unsigned)(size_t)lds + (unsigned)(((wm * 64 + l31) * BK + ((h ^ sw) * 8)) * 2);
+    unsigned ra1 = (unsigned)(size_t)lds + (unsigned)(((wm * 64 + l31) * BK + (((2 + h) ^ sw) * 8)) * 2);
+    const unsigned fbd = (unsigned)((BM + wn * 128 - wm * 64) * BK * 2);              // B fragment row - A fragment row
+    unsigned rb0 = ra0 + fbd, rb1 = ra1 + fbd;
     const bool active = m0 + wm * 64 < g.M;
-    // Block-scaled A (g.bscale): the scale of a row changes from one K segment to the next (the same boundaries for every
-    // row).  The accumulators are kept in units of the current segment's scale and rescaled -- by an exact power of two --
-    // when a boundary is crossed.
+
+    // block-scaled A: the scales of the segments this slab crosses, for the tile's rows, into LDS
     const float *bs = g.bscale;                    // batch 1 only (checked by the launcher)
-    int seg = 0, seg_end = 1 << 30;                // current segment and the k at which it ends
+    int seg0 = 0, seg = 0, seg_end = 1 << 30;
     if (bs) {
-        const int col = kbeg / g.segLinP, in = kbeg % g.segLinP;
-        seg = col * g.segChunks + in / 1024;
-        const int e1 = col * g.segLinP + (in / 1024 + 1) * 1024, e2 = (col + 1) * g.segLinP;
-        seg_end = e1 < e2 ? e1 : e2;
+        seg0 = seg = cc2_seg_of(kbeg, g.segLinP, g.segChunks);
+        seg_end = cc2_seg_end(kbeg, g.segLinP);
+        const int nseg = cc2_seg_of(kbeg + Kper - 1, g.segLinP, g.segChunks) - seg0 + 1;
+        for (int e = tid; e < nseg * BM; e += 512) {
+            int row = m0 + (e & (BM - 1));
+            row = row < g.M ? row : g.M - 1;
+            sctab[e] = bs[(long)(seg0 + (e >> 8)) * g.M + row];
+        }
     }
+    const int srow = wm * 64 + 4 * h;              // first of the lane's accumulator rows inside the tile
+
+    // fragment registers: A of the even / odd half step ([row block][piece]), B of the even / odd unit ([column block][piece])
+    f16x8 Ae[2][2], Ao[2][2], Bx[2][2], By[2][2];
+#define CC_RD(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
     CC_DMA(0, 0);
-    __syncthreads();                               // drains the DMA (vmcnt(0)) of every wave
-    for (int kt = 0; kt < nk; ++kt) {
-        if (kt + 1 < nk) CC_DMA(kt + 1, (kt + 1) & 1);   // the other stage was last read before the previous barrier
-        const unsigned short *st = lds + (kt & 1) * STAGE;
-        if (bs && kbeg + kt * BK >= seg_end) {     // workgroup-uniform
-            const int k = kbeg + kt * BK, col = k / g.segLinP, in = k % g.segLinP;
-            const int nseg = col * g.segChunks + in / 1024;
-            const int e1 = col * g.segLinP + (in / 1024 + 1) * 1024, e2 = (col + 1) * g.segLinP;
-            seg_end = e1 < e2 ? e1 : e2;
-            if (active) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                        row = row < g.M ? row : g.M - 1;
-                        const float ratio = bs[(long)seg * g.M + row] / bs[(long)nseg * g.M + row];
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j][r] *= ratio;
-                    }
-            }
-            seg = nseg;
-        }
-        if (active)
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2) {
-            const int ch = ((2 * s2 + h) ^ sw) * 8;
-            f16x8 a[2][2], bq[4][2];
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) a[i][q] = *reinterpret_cast<const f16x8 *>(st + q * PIECE + fa + i * 32 * BK + ch);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) bq[j][q] = *reinterpret_cast<const f16x8 *>(st + q * PIECE + fb + j * 32 * BK + ch);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    f32x16 c = acc[i][j];
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][1], bq[j][0], c, 0, 0, 0);   // l*h
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bq[j][1], c, 0, 0, 0);   // h*l
-                    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][0], bq[j][0], c, 0, 0, 0);   // h*h
-                    acc[i][j] = c;
-                }
-        }
-        __syncthreads();                           // next stage complete (vmcnt(0)), this one free
+    if (nk > 1) {
+        CC_DMA(1, 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // stage 0 landed (one in-order counter)
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    __syncthreads();                               // also publishes sctab
+    if (active && !(CC_EXP & 2)) {                 // unit 0 of stage 0
+        CC_RD(Ae[0][0], ra0, 0); CC_RD(Ae[1][0], ra0, 32 * BK * 2); CC_RD(Ae[0][1], ra0, PIECE * 2); CC_RD(Ae[1][1], ra0, PIECE * 2 + 32 * BK * 2);
+        CC_RD(Bx[0][0], rb0, 0); CC_RD(Bx[1][0], rb0, 32 * BK * 2); CC_RD(Bx[0][1], rb0, PIECE * 2); CC_RD(Bx[1][1], rb0, PIECE * 2 + 32 * BK * 2);
+        CC_WAIT(Ae, Bx);
+    }
+    if (!active) {
+        // ragged last row tile: this wave's 64 rows lie beyond M; it only moves data (same barriers, same DMA pieces)
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            const int kd = kt + 2 < nk ? kt + 2 : nk - 1;
+            CC_DMA(kd, kt & 1);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        return;
+    }
+    Cc2Loop L{baseA, baseB, pA2, pB2, ldsw, nk, kbeg, bs ? sctab : nullptr, seg0, seg, seg_end, g.segLinP, g.segChunks};
+    cc2_mainloop(acc, Ae, Ao, Bx, By, ra0, ra1, rb0, rb1, offA, offB, srow, L);
+    seg = L.seg;
 #undef CC_DMA
+#undef CC_RD
     if (active) {
         char *Cb = reinterpret_cast<char *>(g.C + (long)b * g.sC + (long)sk * g.sCsplit + (long)m0 * g.ldc + n0);
         const unsigned ldc4 = (unsigned)(g.ldc * 4);
-        unsigned o_ = (unsigned)(wm * 64 + 4 * h) * ldc4 + (unsigned)(wn * 128 + l31) * 4u;
-        // undo both operand scales (powers of two: exact): A was split row by row with the scale of its row maximum
+        unsigned o_ = (unsigned)srow * ldc4 + (unsigned)(wn * 128 + l31) * 4u;
+        // undo both operand scales (powers of two: exact)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             float rsc[16];                 // the 16 row scales of this half requested together
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int lr = srow + i * 32 + (r & 3) + 8 * (r >> 2);
+                int row = m0 + lr;
                 row = row < g.M ? row : g.M - 1;
-                rsc[r] = bs ? bs[(long)seg * g.M + row] : f16x2_scale_of(__uint_as_float(g.amax[(long)b * g.M + row]));
+                rsc[r] = bs ? sctab[(seg - seg0) * BM + lr] : f16x2_scale_of(__uint_as_float(g.amax[(long)b * g.M + row]));
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const int row = m0 + srow + i * 32 + (r & 3) + 8 * (r >> 2);
                 const float sc = rsc[r] * g.sB16;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -207,10 +349,18 @@ int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g) {
     if (g.bscale && (g.batch != 1 || g.segLinP < BK || g.segLinP % BK || g.segChunks != (g.segLinP + 1023) / 1024 || g.K % g.segLinP))
         return (int)hipErrorInvalidValue;
     if ((double)(BM + 1) * (double)g.ldc * 4.0 >= 2147483648.0) return (int)hipErrorInvalidValue;
+    // the DMA addresses a row by a 32-bit byte offset from the operand's base
+    if ((double)g.M * (double)g.lda * 2.0 >= 4294967296.0 || (double)g.N * (double)g.ldb * 2.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
+    if (g.bscale) {            // the scales of the K segments a slab crosses sit in LDS
+        auto seg_of = [&](int k) { return (k / g.segLinP) * g.segChunks + (k % g.segLinP) / 1024; };
+        const int Kper = g.K / g.splitK;
+        for (int sk = 0; sk < g.splitK; ++sk)
+            if (seg_of(sk * Kper + Kper - 1) - seg_of(sk * Kper) + 1 > CC2_MAXSEG) return (int)hipErrorInvalidValue;
+    }
     const long total = (long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch * g.splitK;
     dim3 grid((unsigned)(8 * ((total + 7) / 8)));
     static unsigned long long attr_done = 0;
-    if (int e = ensure_dynamic_lds(gemm_nt_f16x2_cc_kernel, LDS_BYTES, attr_done)) return e;
-    hipLaunchKernelGGL(gemm_nt_f16x2_cc_kernel, grid, dim3(512), LDS_BYTES, stream, g);
+    if (int e = ensure_dynamic_lds(gemm_nt_f16x2_cc_kernel, LDS2_BYTES, attr_done)) return e;
+    hipLaunchKernelGGL(gemm_nt_f16x2_cc_kernel, grid, dim3(512), LDS2_BYTES, stream, g);
     return (int)hipGetLastError();
 }
