@@ -224,12 +224,7 @@ def main():
             if name.startswith("gemm_wblur"):
                 if os.environ.get("SURFH_WBLUR_FP32") == "1":
                     return "gemm_f32_kernel<128, 128>"
-                if os.environ.get("SURFH_WBLUR_PC") == "0":
-                    return "gemm_nt_bf16x3_kernel"
-                if os.environ.get("SURFH_WBLUR_F16") == "0":
-                    return "gemm_nt_bf16x3_pc_kernel"
-                cc = os.environ.get("SURFH_WBLUR_CC", "2")
-                return "gemm_nt_f16x2_cc_kernel" if (cc == "2" or (cc == "1" and name.endswith("adj"))) else "gemm_nt_f16x2_pc_kernel"
+                return "gemm_nt_f16x2_cc_kernel"
             if name.startswith("specmix_"):       # interleaved spectra where the two-piece fp16 passes run (dft_h2.hip)
                 return name + ("_ilv_kernel" if any(k.startswith("dft_h2_") for k in prof_all) else "_kernel")
             if name.startswith("dft_h2_"):
@@ -278,7 +273,7 @@ def main():
                 flops_step = sum(2.0 * 2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
                                  for c in m.channels)
                 ach = flops_step / per_step / avg_s / 1e12
-                nprod = 3.0 if dom.startswith("gemm_nt_f16x2") else 6.0 if dom.startswith("gemm_nt_bf16x3") else 1.0
+                nprod = 3.0 if dom.startswith("gemm_nt_f16x2") else 1.0
                 peak = MFMA_16BIT_PEAK_TF if nprod > 1.0 else MFMA_F32_PEAK_TF
                 roof = {"bound": "mfma", "achieved": nprod * ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": nprod * ach / peak, "traffic": traffic, "kernel": dom, "launches": cnt,

@@ -1,5 +1,7 @@
-// Symmetry-folded 1-D DFT pass on the bf16 matrix cores with exact 3-way operand splitting
-// (arithmetic: gemm_bf16x3.hip), register-direct data operand.
+// Symmetry-folded 1-D DFT pass on the bf16 matrix cores with exact 3-way operand splitting, register-direct data operand.
+// Arithmetic: every fp32 operand is cut into three bf16 pieces by truncating successive remainders (24 mantissa bits = 3 x 8,
+// so x = h + m + l exactly); six of the nine partial products are kept (hh, hm, mh, hl, lh, mm; the dropped ones are below
+// 2^-23 relative, the size of the fp32 product rounding) and accumulated in fp32 by v_mfma_f32_32x32x16_bf16.
 //
 //   acc1 = A[0] * B1,  acc2 = A[1] * B2        one K loop, two products
 //   B_s[k] = X_s[k] + f_s * X_s[Kn-k]          f_s = +1 / -1 / 0 (0: plain rows; no mirror for k = 0 and 2k = Kn,

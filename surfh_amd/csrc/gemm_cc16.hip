@@ -1,15 +1,27 @@
-// Two-piece fp16 NT GEMM, all-consumer form: C[m][n] = sum_k A[m][k] * B[n][k], both operands given as their fp16 pieces
-// (arithmetic of gemm_pc16.hip).  With the matrix-core work halved, the 128 x 256 producer / consumer tile is bound by
-// operand delivery (48 KB per K step = 60 B/clk per CU, the width of the L1 fill path).  Here one workgroup = 8 waves = one
-// 256 x 256 tile (wave tile 64 x 128, 4 x 2 waves): 64 KB of operands per K step for twice the flops, delivered by LDS-DMA
-// (global_load_lds, no registers, no VALU) into the same XOR-swizzled [piece][row][32 k] image, two 64 KB stages.
+// Two-piece fp16 NT GEMM on the matrix cores: C[m][n] = sum_k A[m][k] * B[n][k], both operands given as their fp16 pieces.
+//
+// Arithmetic.  Every operand is scaled by a power of two so that its largest magnitude sits at 2^14, then cut into two fp16
+// values by round-to-nearest:  x / s = h + l + e,  |l| <= 2^-11 |h|,  |e| <= 2^-23 |x / s|  (22 mantissa bits; below 2^-18
+// of the largest magnitude the relative precision decreases, the absolute error stays under 2^-39 of the largest
+// magnitude).  Three products are kept (lh, hl, hh -- each exact in fp32, accumulated in fp32 by v_mfma_f32_32x32x16_f16);
+// the dropped l*l and the remainders e are 2^-22 relative with random sign.  Measured against float64 the split error is
+// 3e-9 (L2) for half the matrix-core work of a three-piece bf16 split; what remains is the fp32 accumulation itself.
+//   * B is constant on this path (the spectral PSF): split once at plan creation (launch_split2h), scale sB16 a host constant.
+//   * A is data: one scale PER ROW (launch_split_rows2h, amax) or per (row, K segment) (the gather writes the pieces itself,
+//     bscale), so that an outlier in one row (a hot detector pixel) does not cost the other rows their precision.
+//
+// Tile.  One workgroup = 8 consumer waves = one 256 x 256 tile (wave tile 64 x 128, 4 x 2 waves): 64 KB of operands per K
+// step of 32, delivered by LDS-DMA (global_load_lds, no registers, no VALU) into an XOR-swizzled [piece][row][32 k] image,
+// two 64 KB stages.  (A 128 x 256 producer / consumer tile needs 48 KB per K step for half the flops: 60 B/clk per CU, the
+// width of the L1 fill path.)
 // Results are the same bits as the first (compiler-scheduled) version of this kernel: same products, same order.
 #include "gemm_f32.h"
 #include "lds_attr.h"
-#include <cstdlib>
+#include <cmath>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
@@ -31,7 +43,6 @@ __device__ __forceinline__ float f16x2_scale_of(float amax) {
 // dst[q*plane + row*ld + k] = fp16 piece q of src[row*ld + k] / scale(rowmax[row]), round to nearest; ld multiple of 4
 __global__ __launch_bounds__(256) void split_rows2h_kernel(const float *__restrict__ src, const unsigned *__restrict__ rowmax,
                                                            unsigned short *__restrict__ dst, int ld, long plane) {
-    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
     const int row = blockIdx.y;
     const float inv = 1.f / f16x2_scale_of(__uint_as_float(rowmax[row]));
     const int k4 = (blockIdx.x * 256 + threadIdx.x) * 4;
@@ -333,7 +344,40 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     }
 }
 
+// dst[q*plane + i] = fp16 piece q of src[i] * inv (round to nearest), four elements per thread
+__global__ __launch_bounds__(256) void split2h_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, long n4, long plane,
+                                                      float inv) {
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+        const float4 v = reinterpret_cast<const float4 *>(src)[i];
+        const float x0 = v.x * inv, x1 = v.y * inv, x2 = v.z * inv, x3 = v.w * inv;
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
+        f16x4 h = {h0, h1, h2, h3};
+        f16x4 l = {(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1), (_Float16)(x2 - (float)h2), (_Float16)(x3 - (float)h3)};
+        *reinterpret_cast<f16x4 *>(dst + 4 * i) = h;
+        *reinterpret_cast<f16x4 *>(dst + plane + 4 * i) = l;
+    }
+}
+
 }  // namespace
+
+float gemm_f16x2_scale(float amax) {
+    if (!(amax > 0.f)) return 1.f;
+    int e = 0;
+    std::frexp(amax, &e);                  // amax = f * 2^e, f in [0.5, 1)  ->  floor(log2(amax)) = e - 1
+    int s = (e - 1) - 13;
+    s = s < -126 ? -126 : (s > 127 ? 127 : s);
+    return std::ldexp(1.f, s);
+}
+
+int launch_split2h(hipStream_t stream, const float *src, unsigned short *dst2, long n, long plane, float scale) {
+    if (n % 4 || plane % 4 || !(scale > 0.f)) return (int)hipErrorInvalidValue;
+    const long n4 = n / 4;
+    long nb = (n4 + 255) / 256;
+    hipLaunchKernelGGL(split2h_kernel, dim3((unsigned)(nb > 4096 ? 4096 : (nb < 1 ? 1 : nb))), dim3(256), 0, stream, src, dst2, n4, plane,
+                       1.f / scale);
+    return (int)hipGetLastError();
+}
 
 int launch_split_rows2h(hipStream_t stream, const float *src, const unsigned *rowmax, unsigned short *dst2, int rows, int ld, long plane) {
     if (ld % 4 || plane % 4 || rows < 1) return (int)hipErrorInvalidValue;

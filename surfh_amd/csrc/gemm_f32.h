@@ -23,17 +23,14 @@ struct GemmArgs {
     int splitK = 1;                // >1: K is cut in splitK slabs, slab s is written to C + s*sCsplit
     long sCsplit = 0;
     int accumulate = 0;            // 1: C += A*B (only with splitK==1)
-    // producer/consumer kernel only: operands already cut into their three bf16 pieces (launch_split3), piece q of
-    // element (m,k) at A3[q*pA3 + m*lda + k].  B3 alone (a constant operand split once) or both may be given.
-    const unsigned short *A3 = nullptr, *B3 = nullptr;
-    long pA3 = 0, pB3 = 0;
-    // two-piece fp16 kernel (gemm_pc16.hip): B as its fp16 pieces B16[q*pB16 + n*ldb + k] of B / sB16; the scales of A
-    // (one per row) derived on the device from amax[batch][M] = max |A[m][:]| as bit patterns
-    const unsigned short *B16 = nullptr;
-    long pB16 = 0;
+    // two-piece fp16 kernel (gemm_cc16.hip): both operands as fp16 pieces, piece q of element (m, k) at A3[q*pA3 + m*lda + k]
+    // (A / scale of its row) and B16[q*pB16 + n*ldb + k] (B / sB16); the scales of A (one per row) are derived on the device
+    // from amax[batch][M] = max |A[m][:]| as bit patterns
+    const unsigned short *A3 = nullptr, *B16 = nullptr;
+    long pA3 = 0, pB16 = 0;
     float sB16 = 0.f;
     const unsigned *amax = nullptr;
-    // all-consumer kernel, alternative to amax: A's pieces carry one scale per (row, K segment) -- bscale[segment][M] with
+    // alternative to amax: A's pieces carry one scale per (row, K segment) -- bscale[segment][M] with
     // segment(k) = (k / segLinP) * segChunks + (k % segLinP) / 1024 (what launch_spmm_rows_f16 writes)
     const float *bscale = nullptr;
     int segLinP = 0, segChunks = 0;
@@ -44,23 +41,11 @@ int launch_gemm_f32(hipStream_t stream, const GemmArgs &g);
 // the same product with float64 accumulation (plain vector arithmetic; surfh_config.verify)
 int launch_gemm_f64acc(hipStream_t stream, const GemmArgs &g);
 
-// C[M][N] = A[M][K] * B[N][K]^T on the bf16 matrix cores with exact 3-way operand splitting (fp32-accurate,
-// see gemm_bf16x3.hip).  B0/ldb describe B as [N][K]; M, N multiples of 128.
-int launch_gemm_nt_bf16x3(hipStream_t stream, const GemmArgs &g);
-
-// The same product with a producer / consumer workgroup (8 waves, 128 x 256 tile, one workgroup per CU: gemm_pc3.hip).
-// N may be any multiple of 128.
-int launch_gemm_nt_bf16x3_pc(hipStream_t stream, const GemmArgs &g);
-
-// dst3[q*plane + i] = piece q (h, m, l) of src[i], the exact truncation split of gemm_bf16x3.hip; n multiple of 4
-int launch_split3(hipStream_t stream, const float *src, unsigned short *dst3, long n, long plane);
-
-// Two-piece fp16 form of the producer/consumer GEMM (half the matrix-core work of the bf16 split, see gemm_pc16.hip)
-int launch_gemm_nt_f16x2_pc(hipStream_t stream, const GemmArgs &g);
 // dst2[q*plane + i] = fp16 piece q (h, l) of src[i] / scale (round to nearest); scale from gemm_f16x2_scale(max |src|)
 int launch_split2h(hipStream_t stream, const float *src, unsigned short *dst2, long n, long plane, float scale);
 float gemm_f16x2_scale(float amax);
-// All-consumer form (gemm_cc16.hip): 256 x 256 tile, eight consumer waves, both operands as fp16 pieces delivered by LDS-DMA.
+// C[M][N] = A[M][K] * B[N][K]^T as two-piece fp16 products (gemm_cc16.hip): 256 x 256 tile, eight consumer waves, both
+// operands as fp16 pieces delivered by LDS-DMA.  M multiple of 64, N of 128, K of 32 * splitK.
 // A3 / pA3 = pieces of A split row by row with the scales of amax[M] (launch_split_rows2h); B16 / pB16 / sB16 as above.
 int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g);
 int launch_split_rows2h(hipStream_t stream, const float *src, const unsigned *rowmax, unsigned short *dst2, int rows, int ld, long plane);

@@ -42,10 +42,6 @@ struct EllTable {
     // this pass and are read-modify-written, all others are plain stores -- the destination then needs NO clearing (takes precedence)
     const int2 *rng = nullptr;
 };
-// pmax ... rowmax (optional, gather mode only): every wave stores max |output| (bit pattern) in its entry of pmax
-// [spmm_rows_waves()]; a second pass takes, for every row of the [NP][K] operand the table writes, the maximum over the
-// entries listed in rowptr / idx (built once with spmm_rows_entry) -- the per-row scales of the data operand of the
-// two-piece fp16 GEMM (gemm_pc16.hip)
 // Scatter table with its rows taken SCATTER_G at a time: neighbouring cube pixels receive from almost the same operand
 // rows, so a group reads the union of its members' taps once and applies one weight per member (0 where a member does not
 // use the tap).  dst < 0 marks a missing member.
@@ -66,10 +62,7 @@ int launch_spmm_group_scatter(hipStream_t s, const GroupTable &t, const float *s
 int launch_spmm_group_gather_f16(hipStream_t s, const GroupTable &t, const float *src, unsigned short *dst16, long plane, int nlam,
                                  float *bscale, int NP, long K, int LinP);
 
-int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate,
-                     unsigned *pmax = nullptr, const int *rowptr = nullptr, const int *idx = nullptr, unsigned *rowmax = nullptr,
-                     int NP = 0);
-long spmm_rows_waves(const EllTable &t, int nlam);
+int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate);
 // the gather writing its [NP][K] output as two fp16 pieces dst16[q*plane + ...] of value / block scale; one power-of-two
 // scale per workgroup, i.e. per (row, segment) with segment = (column / LinP) * nchunk + (column % LinP) / 1024, nchunk =
 // ceil(LinP / 1024): bscale[segment][NP] (entries of segments the table never writes must be 1)
@@ -77,7 +70,6 @@ int launch_spmm_rows_f16(hipStream_t s, const EllTable &t, const float *src, uns
                          int NP, long K, int LinP);
 int launch_dequant_f16x2(hipStream_t s, const unsigned short *src16, long plane, const float *bscale, float *dst, int NP, long K, int LinP,
                          int nchunk);
-long spmm_rows_entry(const EllTable &t, int r, int chunk, int wave);
 long ymat_from_y_waves(int PS, int Ldet, int aout);
 
 // [L][Na][Nb] (wavelength-major, the reference's cube layout) <-> [NBP][NAP][LP] (wavelength innermost)

@@ -349,11 +349,9 @@ __global__ __launch_bounds__(TPB) void wct_solve_kernel(const float *__restrict_
 // ---------------------------------------------------------------------------------------------
 // sparse row gather vectorised over wavelength: one workgroup = one table row x 1024 wavelengths
 // ---------------------------------------------------------------------------------------------
-// max over the wave of a non-negative value, then one atomicMax per wave into one of 64 slots
-// max |value| of a kernel's output for the two-piece fp16 GEMM's operand scale: every wave stores its maximum (bit pattern
-// of a non-negative float) in its own entry of `pmax`, one small workgroup reduces the entries afterwards.  (atomicMax
-// into 64 shared slots serialised in L2 at about 140 ns each and made the gather 3.5x slower; reading the slot first and
-// issuing the atomic only when it raises the value still cost 45 %, because the first wavefront of waves all see zero.)
+// max |value| of ymat for the per-row operand scales of the two-piece fp16 GEMM: every wave stores its maximum (bit pattern
+// of a non-negative float) in its own entry of `pmax`, one small workgroup reduces the entries afterwards (no atomics:
+// atomicMax into shared slots serialises in L2 at about 140 ns each).
 __device__ __forceinline__ void wave_amax_store(float m, unsigned *pmax, unsigned wave_id) {
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     if ((threadIdx.x & 63) == 0) pmax[wave_id] = __float_as_uint(m);
@@ -370,20 +368,8 @@ __global__ __launch_bounds__(TPB) void rowmax_contiguous_kernel(const unsigned *
     rowmax[n] = m;                                                   // padding rows of the operand are zero
 }
 
-// gather: the per-wave entries of a GEMM row are scattered over the launch grid; their indices were listed at plan creation
-// (rowptr / idx).  One wave per row, no atomics (an atomicMax per wave inside the gather cost 0.1 ms per launch).
-__global__ __launch_bounds__(TPB) void rowmax_csr_kernel(const unsigned *__restrict__ pmax, const int *__restrict__ rowptr,
-                                                         const int *__restrict__ idx, int NP, unsigned *__restrict__ rowmax) {
-    const int row = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (row >= NP) return;
-    unsigned m = 0;
-    for (int e = rowptr[row] + lane; e < rowptr[row + 1]; e += 64) m = max(m, pmax[idx[e]]);
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if (lane == 0) rowmax[row] = m;
-}
-
 __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float *__restrict__ src,
-                                                        float *__restrict__ dst, int nlam, int accumulate, unsigned *pmax) {
+                                                        float *__restrict__ dst, int nlam, int accumulate) {
     // workgroups are dealt round-robin over the 8 XCDs (each with its own L2): give every XCD one
     // contiguous band of table rows, so neighbouring rows -- which share most of their taps -- hit the same L2
     const int per = (t.R + 7) / 8;
@@ -422,9 +408,6 @@ __global__ __launch_bounds__(TPB) void spmm_rows_kernel(EllTable t, const float 
         }
         *p = acc;
     }
-    if (pmax)       // lanes beyond the window carry 0; the whole wave takes part in the reduction
-        wave_amax_store(fmaxf(fmaxf(fabsf(acc.x), fabsf(acc.y)), fmaxf(fabsf(acc.z), fabsf(acc.w))), pmax,
-                        (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
 // verification twin of spmm_rows_kernel: the same rows with float64 accumulation (surfh_config.verify)
@@ -1067,24 +1050,11 @@ __global__ __launch_bounds__(TPB) void lmm_cube2maps_kernel(const float *__restr
 
 long ymat_from_y_waves(int PS, int Ldet, int aout) { return (long)((Ldet + TPB - 1) / TPB) * PS * aout * (TPB / 64); }
 
-long spmm_rows_waves(const EllTable &t, int nlam) {
-    return (long)((t.R + 7) / 8 * 8) * ((nlam / 4 + TPB - 1) / TPB) * (TPB / 64);
-}
-// index of the pmax entry of wave `wave` of the workgroup that handles table row r, chunk `chunk` (the kernel's XCD banding)
-long spmm_rows_entry(const EllTable &t, int r, int chunk, int wave) {
-    const int per = (t.R + 7) / 8, gx = (t.R + 7) / 8 * 8;
-    const int bx = (r % per) * 8 + r / per;
-    return ((long)chunk * gx + bx) * (TPB / 64) + wave;
-}
-
-int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate, unsigned *pmax,
-                     const int *rowptr, const int *idx, unsigned *rowmax, int NP) {
+int launch_spmm_rows(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate) {
     if (t.R == 0 || nlam <= 0) return 0;
-    if (nlam % 4 || (pmax && (accumulate || !rowptr || !idx || !rowmax || NP <= 0))) return (int)hipErrorInvalidValue;
+    if (nlam % 4) return (int)hipErrorInvalidValue;
     dim3 grid((t.R + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate, pmax);
-    if (pmax)
-        hipLaunchKernelGGL(rowmax_csr_kernel, dim3((NP + TPB / 64 - 1) / (TPB / 64)), dim3(TPB), 0, s, pmax, rowptr, idx, NP, rowmax);
+    hipLaunchKernelGGL(spmm_rows_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam, accumulate);
     return (int)hipGetLastError();
 }
 

@@ -97,16 +97,12 @@ struct Channel {
     int K = 0, NP = 0, LdetP = 0, splitK = 1;
     long yoff = 0, ysize = 0;
     float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
-    unsigned short *W3 = nullptr, *Wt3 = nullptr;   // the two constant GEMM operands cut once into their bf16 pieces [3][rows][cols]
     unsigned short *W16 = nullptr, *Wt16 = nullptr; // ... or into their two fp16 pieces [2][rows][cols] of W / sW (gemm_pc16.hip)
     unsigned short *Xs16 = nullptr, *ymat16 = nullptr;   // the data operands as fp16 pieces (all-consumer kernel, gemm_cc16.hip)
     float *bscale = nullptr;                        // Xs16's scales, one per (row, K segment): [nbs * ceil(LinP/1024)][NP]
     float sW = 1.f;
     unsigned *amax = nullptr;                       // [2][NP] max |row| of the data operands: Xs (forward), ymat (adjoint)
     unsigned *pmax = nullptr;                       // per-wave maxima of the kernel that wrote the operand (reduced into amax)
-    long pmax_adj = 0;                              // the adjoint's entries follow the forward's
-    int *rm_ptr = nullptr, *rm_idx = nullptr;       // forward: pmax entries of every GEMM row (CSR)
-    std::vector<int64_t> fwd_dst;                   // destinations of the gather rows, kept until the CSR is built
     DevEll fwd, adjT, adjRef;
     HostEll adjT_host;                  // kept until the grouped scatter table is built (plan creation)
     bool has_ref = false;
@@ -149,14 +145,10 @@ struct surfh_plan {
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
     int n_cu = 256;
     int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
-    bool wblur_pc = true;                        // spectral-blur GEMMs on the producer/consumer kernel (gemm_pc3.hip)
-    bool wblur_presplit = true;                  // ... with the constant operand W split once at plan creation
-    bool wblur_f16 = true;                       // spectral-blur GEMMs as two-piece fp16 products (gemm_pc16.hip), half the MFMA work
     bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
     bool scatter_grouped = true;                 // adjoint scatter with SCATTER_G neighbouring pixels per workgroup (GroupTable)
     bool gather_grouped = true;                  // forward gather (fp16 output) likewise
-    int wblur_cc = 2;                            // all-consumer 256 x 256 GEMM (gemm_cc16.hip): 0 off, 1 adjoint only, 2 both directions
-    bool dense_dft = false, fold2 = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
+    bool dense_dft = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
     // surfh_config.verify: every long sum accumulated in float64 (dense DFT products, spectral blur, adjoint spectral mix,
     // gather / scatter rows) -- the strict dot test; storage stays fp32
     bool verify = false;
@@ -469,7 +461,6 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
         f = std::move(g);
     }
     if (upload_ell(f, &c->fwd)) return 1;
-    c->fwd_dst = f.dst;
     if (p->gather_grouped && p->gather_sorted && !c->bsum) {      // SCATTER_G rows neighbouring in cube-location order per workgroup
         std::vector<std::pair<size_t, size_t>> runs;
         for (size_t r = 0; r < f.rows.size(); r += SCATTER_G) runs.push_back({r, std::min<size_t>(SCATTER_G, f.rows.size() - r)});
@@ -553,15 +544,14 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     return 0;
 }
 
-int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu, int max_steps = 34, int tile_m = 128, int tile_n = 256) {
+int pick_split(const Channel &c, int forced, bool f16, int n_cu) {
     if (forced > 0) return (c.K % (32 * forced) == 0) ? forced : 1;
-    if (pc_kernel) {
-        // producer/consumer kernel (128 x 256 tiles, one workgroup per CU).  The slab length is set by accuracy first:
-        // accumulation chains of the split-bf16 products stay unbiased up to about 1024 k (gemm_pc3.hip header), so
-        // take the fewest slabs with K / s <= 1088; among slab counts up to 1.5x that, the one that fills the last
-        // round of workgroups best.  The two-piece fp16 products have no small terms to lose: measured bias on non-negative
-        // operands -1.3e-7 for one 4096-long chain (plain fp32 accumulation), so they run chains of up to 4352 k
-        // (max_steps 136): a quarter of the slabs to sum.
+    if (f16) {
+        // two-piece fp16 kernel (256 x 256 tiles, one workgroup per CU).  The slab length is set by accuracy first: one fp32
+        // accumulation chain of 4096 non-negative products shows a bias of -1.3e-7 (three-piece bf16 products lost their
+        // small terms beyond about 1024 k), so chains run up to 4352 k (136 K steps); beyond the fewest such slabs, any
+        // divisor that leaves at least 16 K steps per slab and fills the last round of workgroups best.
+        constexpr int max_steps = 136, tile_m = 256, tile_n = 256;
         const long tiles = (long)((c.NP + tile_m - 1) / tile_m) * ((c.LdetP + tile_n - 1) / tile_n);
         const int steps = c.K / 32;
         int smin = 0;
@@ -570,10 +560,7 @@ int pick_split(const Channel &c, int forced, bool pc_kernel, int n_cu, int max_s
         if (!smin) return 1;
         int best = smin;
         double best_t = -1.0;
-        // bf16 form: up to 1.5x the minimum (its chains should stay long enough to amortise the slab sum); the fp16 forms
-        // (max_steps > 34) may cut much finer to fill the CUs: any divisor leaving at least 16 K steps per slab
-        const int smax = max_steps > 34 ? steps / 16 : smin + smin / 2;
-        for (int s = smin; s <= smax && s <= steps; ++s) {
+        for (int s = smin; s <= steps / 16 && s <= steps; ++s) {
             if (steps % s) continue;
             const double t = (double)((tiles * s + n_cu - 1) / n_cu) * (steps / s) + 3.0 * s;
             if (best_t < 0 || t < best_t) { best_t = t; best = s; }
@@ -878,7 +865,7 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
         Prof pr(p, "dft_fold_rows_fwd");
         LAUNCH_OK(launch_dft_fold(p->stream, g));
     }
-    if (!p->fold2) {   // c2c along alpha, all four folded products in one workgroup, batched over k_beta
+    {   // c2c along alpha, all four folded products in one workgroup, batched over k_beta
         DftFold4Args h;
         h.Cm = p->Cma; h.Sm = p->Sma; h.lda = p->KPa;
         h.src_r = p->ycol; h.src_i = p->ycol + (long)p->KBP * p->NAP * LP; h.ldb = LP; h.sB = p->NAP * LP;
@@ -886,20 +873,6 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
         h.sgn = -1.f; h.Nn = p->Na; h.rvalid = ha; h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
         Prof pr(p, "dft_fold_cols_fwd");
         LAUNCH_OK(launch_dft_fold4(p->stream, h));
-        return 0;
-    }
-    for (int z = 0; z < 2; ++z) {   // c2c along alpha, one launch per output component, batched over k_beta
-        DftFoldArgs h;
-        h.A[0] = z ? p->Sma : p->Cma; h.A[1] = z ? p->Cma : p->Sma; h.lda = p->KPa;
-        h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->KBP * p->NAP * LP; h.ldb = LP; h.sB = p->NAP * LP;
-        h.fold[0] = z ? -1.f : 1.f; h.fold[1] = z ? 1.f : -1.f; h.Kn = p->Na;
-        h.dst[0] = dst + (long)z * p->PL * LP; h.ldc = p->KBP * LP; h.sC = LP;
-        h.mode = 0; h.Rn = p->Na; h.rvalid = ha;
-        if (z == 0) { h.e00 = 1.f; h.e01 = 1.f; h.e10 = 1.f; h.e11 = -1.f; }
-        else        { h.e00 = -1.f; h.e01 = 1.f; h.e10 = 1.f; h.e11 = 1.f; }
-        h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
-        Prof pr(p, "dft_fold_cols_fwd");
-        LAUNCH_OK(launch_dft_fold(p->stream, h));
     }
     return 0;
 }
@@ -909,7 +882,7 @@ int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = fals
     if (p->rx3) return irfft2_lam_rx3(p, src, dst, mix);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
-    if (!p->fold2) {   // c2c along alpha; with `mix` the source spectrum is formed on the fly as sotf * sum_t tpl * mhat
+    {   // c2c along alpha; with `mix` the source spectrum is formed on the fly as sotf * sum_t tpl * mhat
         DftFold4Args g;
         g.Cm = p->Cma; g.Sm = p->Sma; g.lda = p->KPa;
         g.src_r = src; g.src_i = src + p->PL * LP; g.ldb = p->KBP * LP;
@@ -918,19 +891,6 @@ int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = fals
         if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = p->LP; g.PL = p->PL; g.KBP = p->KBP; }
         Prof pr(p, mix ? "dft_fold_cols_inv_mix" : "dft_fold_cols_inv");
         LAUNCH_OK(launch_dft_fold4(p->stream, g));
-    } else
-    for (int z = 0; z < 2; ++z) {   // c2c along alpha
-        DftFoldArgs g;
-        g.A[0] = z ? p->Sma : p->Cma; g.A[1] = z ? p->Cma : p->Sma; g.lda = p->KPa;
-        g.src[0] = src; g.src[1] = src + p->PL * LP; g.ldb = p->KBP * LP;
-        g.fold[0] = z ? -1.f : 1.f; g.fold[1] = z ? 1.f : -1.f; g.Kn = p->Na;
-        g.dst[0] = p->ycol + (long)z * p->NAP * p->KBP * LP; g.ldc = p->KBP * LP;
-        g.mode = 0; g.Rn = p->Na; g.rvalid = ha;
-        if (z == 0) { g.e00 = 1.f; g.e01 = -1.f; g.e10 = 1.f; g.e11 = 1.f; }
-        else        { g.e00 = 1.f; g.e01 = 1.f; g.e10 = -1.f; g.e11 = 1.f; }
-        g.MP = p->MPa; g.KP = p->KPa; g.N = (int)(hb * LP);
-        Prof pr(p, "dft_fold_cols_inv");
-        LAUNCH_OK(launch_dft_fold(p->stream, g));
     }
     DftFoldArgs h;   // c2r along beta, batched over alpha: cube[b] = Gc*Yr - Gs*Yi, cube[N-b] = Gc*Yr + Gs*Yi
     h.A[0] = p->Gc; h.A[1] = p->Gs; h.lda = p->KPb;
@@ -967,7 +927,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
         }
         if (rfft2_cube(p, p->cube, p->mhat)) return 1;
     }
-    if (p->T > 0 && p->fuse_mix && !p->dense_dft && !p->fold2 && !(p->rx3 && p->T > 4)) {
+    if (p->T > 0 && p->fuse_mix && !p->dense_dft && !(p->rx3 && p->T > 4)) {
         // spectral mix x OTF fused into the loader of the first inverse pass: `spec` is never written
         if (irfft2_cube(p, p->sotf, p->cube, true)) return 1;
     } else {
@@ -990,8 +950,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
             else if (p->verify)
                 LAUNCH_OK(launch_spmm_rows_f64acc(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0));
             else
-                LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0, f16 ? c.pmax : nullptr, c.rm_ptr, c.rm_idx,
-                                           f16 ? c.amax : nullptr, c.NP));
+                LAUNCH_OK(launch_spmm_rows(s, c.fwd.t, p->cube, c.Xs, c.nlam, 0));
         }
         if (c.bsum) {   // y[l][(p,s,a)] = Xs[(p,s,a)][l]
             Prof pr(p, "y_transpose");
@@ -1009,15 +968,12 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
                 g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [K][N]
                 LAUNCH_OK(gemm32(p, sB, g));
             } else {
-                g.B0 = c.W; g.ldb = c.K;             // B as [N][K]
-                g.B3 = c.W3; g.pB3 = (long)c.LdetP * c.K;
-                g.B16 = c.W16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
-                if (f16 && c.Xs16) {       // both operands as pieces: 256 x 256 all-consumer kernel
-                    g.A3 = c.Xs16; g.pA3 = (long)c.NP * c.K;
-                    g.amax = nullptr; g.bscale = c.bscale; g.segLinP = c.LinP; g.segChunks = (c.LinP + 1023) / 1024;
-                    LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
-                } else
-                LAUNCH_OK(f16 ? launch_gemm_nt_f16x2_pc(sB, g) : p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
+                // both operands as fp16 pieces (the gather wrote the block-scaled pieces of Xs): 256 x 256 all-consumer kernel
+                g.ldb = c.K;                         // B as [N][K]
+                g.B16 = c.W16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW;
+                g.A3 = c.Xs16; g.pA3 = (long)c.NP * c.K;
+                g.bscale = c.bscale; g.segLinP = c.LinP; g.segChunks = (c.LinP + 1023) / 1024;
+                LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
         }
         {
@@ -1062,8 +1018,8 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
         const bool f16 = c.W16 != nullptr;
         {
             Prof pr(p, "ymat_from_y", sB);
-            LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax + c.pmax_adj : nullptr,
-                                         f16 ? c.amax + c.NP : nullptr, c.NP));
+            LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax : nullptr,
+                                         f16 ? c.amax : nullptr, c.NP));
         }
         GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
         g.A0 = c.ymat; g.lda = c.LdetP;
@@ -1075,15 +1031,11 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
                 g.B0 = c.W; g.ldb = c.K;             // B as [K'=l'][N'=k]
                 LAUNCH_OK(gemm32(p, sB, g));
             } else {
-                g.B0 = c.Wt; g.ldb = c.LdetP;        // B as [N'=k][K'=l']
-                g.B3 = c.Wt3; g.pB3 = (long)c.LdetP * c.K;
-                g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax + c.NP;
-                if (f16 && c.ymat16) {
-                    LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax + c.NP, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));
-                    g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
-                    LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
-                } else
-                LAUNCH_OK(f16 ? launch_gemm_nt_f16x2_pc(sB, g) : p->wblur_pc ? launch_gemm_nt_bf16x3_pc(sB, g) : launch_gemm_nt_bf16x3(sB, g));
+                g.ldb = c.LdetP;                     // B as [N'=k][K'=l']
+                g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
+                LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
+                g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
+                LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
         }
         if (chain(p, sB, s)) return 1;
@@ -1179,8 +1131,6 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipFree(p->cg_hist);
     for (auto &c : p->ch) {
         for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
-        hipFree(c.W3);
-        hipFree(c.Wt3);
         hipFree(c.W16);
         hipFree(c.Wt16);
         hipFree(c.Xs16);
@@ -1188,8 +1138,6 @@ int surfh_plan_destroy(surfh_plan *p) {
         hipFree(c.ymat16);
         hipFree(c.amax);
         hipFree(c.pmax);
-        hipFree(c.rm_ptr);
-        hipFree(c.rm_idx);
         free_ell(&c.fwd);
         free_ell(&c.adjT);
         free_ell(&c.adjRef);
@@ -1283,8 +1231,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
 
     {   // which transform kernels run decides the layout of the complex arrays: two-piece fp16 passes (default where
         // the matrices fit LDS) keep them interleaved
-        const char *eh = getenv("SURFH_DFT_H2"), *er = getenv("SURFH_DFT_RX3"), *ed = getenv("SURFH_DFT_DENSE"), *ef = getenv("SURFH_FOLD2");
-        p->h2 = !cfg->verify && !(eh && eh[0] == '0') && !(er && er[0] == '0') && !(ed && ed[0] == '1') && !(ef && ef[0] == '1') &&
+        const char *eh = getenv("SURFH_DFT_H2"), *er = getenv("SURFH_DFT_RX3"), *ed = getenv("SURFH_DFT_DENSE");
+        p->h2 = !cfg->verify && !(eh && eh[0] == '0') && !(er && er[0] == '0') && !(ed && ed[0] == '1') &&
                 dft_h2_supported(p->Na, p->Nb, p->NAP, p->KBP, p->LP);
     }
     // ---- constants ------------------------------------------------------------------------
@@ -1338,8 +1286,6 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     {   // folded-DFT matrices
         const char *e = getenv("SURFH_DFT_DENSE");
         p->dense_dft = e && e[0] == '1';
-        const char *e2 = getenv("SURFH_FOLD2");
-        p->fold2 = e2 && e2[0] == '1';            // two-launch c2c passes (A/B reference for the fused four-product kernel)
         const char *e3 = getenv("SURFH_NO_FUSED_MIX");
         p->fuse_mix = !(e3 && e3[0] == '1');
         const char *e4 = getenv("SURFH_WBLUR_FP32");
@@ -1351,20 +1297,12 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         if (p->overlap && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
         const char *e8 = getenv("SURFH_DFT_PACKED");
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
-        const char *e6 = getenv("SURFH_WBLUR_PC");
-        p->wblur_pc = !(e6 && e6[0] == '0');      // 0: the 4-wave split-bf16 kernel (gemm_bf16x3.hip)
         const char *e15 = getenv("SURFH_GATHER_GROUPED");
         p->gather_grouped = !(e15 && e15[0] == '0');
         const char *e14 = getenv("SURFH_SCATTER_GROUPED");
         p->scatter_grouped = !(e14 && e14[0] == '0');
-        const char *e13 = getenv("SURFH_WBLUR_CC");
-        if (e13 && e13[0] >= '0' && e13[0] <= '2') p->wblur_cc = e13[0] - '0';
         const char *e12 = getenv("SURFH_GATHER_SORTED");
         p->gather_sorted = !(e12 && e12[0] == '0');   // 0: gather rows in (pointing, alpha, beta) order
-        const char *e11 = getenv("SURFH_WBLUR_F16");
-        p->wblur_f16 = !(e11 && e11[0] == '0');      // 0: the three-piece bf16 kernels
-        const char *e9 = getenv("SURFH_WBLUR_PRESPLIT");
-        p->wblur_presplit = !(e9 && e9[0] == '0');   // 0: the producers split W again in every tile
         const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
         p->MPa = (ha + 127) / 128 * 128; p->KPa = (ha + 15) / 16 * 16;
         p->MPb = (hb + 127) / 128 * 128; p->KPb = (hb + 15) / 16 * 16;
@@ -1460,48 +1398,21 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         c.yoff = yoff;
         yoff += c.ysize;
         if (c.bsum) continue;
-        const bool f16 = p->wblur_pc && !p->wblur_fp32 && p->wblur_f16;
-        c.splitK = p->verify ? 1 : pick_split(c, cfg->split_k_forward, p->wblur_pc && !p->wblur_fp32, p->n_cu, f16 ? 136 : 34,
-                              (f16 && p->wblur_cc == 2) ? 256 : 128, 256);
-        if (p->wblur_pc && !p->wblur_fp32 && p->wblur_f16) {
+        const bool f16 = !p->wblur_fp32;          // spectral-blur GEMMs as two-piece fp16 products (gemm_cc16.hip)
+        c.splitK = p->verify ? 1 : pick_split(c, cfg->split_k_forward, f16, p->n_cu);
+        if (f16) {
             const long nw = (long)c.LdetP * c.K;
-            c.pmax_adj = spmm_rows_waves(c.fwd.t, c.nlam);
-            const long nwv = c.pmax_adj + ymat_from_y_waves(c.P * c.S, c.Ldet, c.aout);
-            {   // pmax entries of every GEMM row: gather row r writes into GEMM row dst / K
-                const int chunks = (c.nlam / 4 + 255) / 256;
-                std::vector<std::vector<int>> per((size_t)c.NP);
-                for (size_t r = 0; r < c.fwd_dst.size(); ++r) {
-                    const long row = c.fwd_dst[r] / c.K;
-                    if (row < 0 || row >= c.NP) return bail(fail("gather destination outside the operand"));
-                    for (int ck = 0; ck < chunks; ++ck)
-                        for (int w = 0; w < 4; ++w) per[row].push_back((int)spmm_rows_entry(c.fwd.t, (int)r, ck, w));
-                }
-                std::vector<int> ptr((size_t)c.NP + 1, 0), idx;
-                for (int m = 0; m < c.NP; ++m) {
-                    ptr[m + 1] = ptr[m] + (int)per[m].size();
-                    idx.insert(idx.end(), per[m].begin(), per[m].end());
-                }
-                if (idx.empty()) idx.push_back(0);
-                if (dev_upload(&c.rm_ptr, ptr) || dev_upload(&c.rm_idx, idx)) return bail(1);
-            }
-            if (dev_alloc(&c.W16, (size_t)2 * nw) || dev_alloc(&c.Wt16, (size_t)2 * nw) || dev_alloc(&c.amax, (size_t)2 * c.NP) ||
-                dev_alloc(&c.pmax, (size_t)nwv))
+            const long nwv = ymat_from_y_waves(c.P * c.S, c.Ldet, c.aout);
+            if (dev_alloc(&c.W16, (size_t)2 * nw) || dev_alloc(&c.Wt16, (size_t)2 * nw) || dev_alloc(&c.amax, (size_t)c.NP) ||
+                dev_alloc(&c.pmax, (size_t)nwv) || dev_alloc(&c.ymat16, (size_t)2 * c.NP * c.LdetP) || dev_alloc(&c.Xs16, (size_t)2 * c.NP * c.K))
                 return bail(1);
             hipMemset(c.pmax, 0, (size_t)nwv * sizeof(unsigned));       // entries of workgroups that exit early stay 0
-            hipMemset(c.amax, 0, (size_t)2 * c.NP * sizeof(unsigned));
-            if (p->wblur_cc >= 1 && dev_alloc(&c.ymat16, (size_t)2 * c.NP * c.LdetP)) return bail(1);
-            if (p->wblur_cc == 2) {
-                if (dev_alloc(&c.Xs16, (size_t)2 * c.NP * c.K)) return bail(1);
-                hipMemset(c.Xs16, 0, (size_t)2 * c.NP * c.K * sizeof(unsigned short));       // padding rows / columns stay zero
-                std::vector<float> ones((size_t)c.nbs * ((c.LinP + 1023) / 1024) * c.NP, 1.f);   // segments never written: scale 1
-                if (dev_upload(&c.bscale, ones)) return bail(1);
-            }
+            hipMemset(c.amax, 0, (size_t)c.NP * sizeof(unsigned));
+            hipMemset(c.Xs16, 0, (size_t)2 * c.NP * c.K * sizeof(unsigned short));       // padding rows / columns stay zero
+            std::vector<float> ones((size_t)c.nbs * ((c.LinP + 1023) / 1024) * c.NP, 1.f);   // segments never written: scale 1
+            if (dev_upload(&c.bscale, ones)) return bail(1);
             if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
                 return bail(fail("operand split failed"));
-        } else if (p->wblur_pc && !p->wblur_fp32 && p->wblur_presplit) {
-            const long nw = (long)c.LdetP * c.K;
-            if (dev_alloc(&c.W3, (size_t)3 * nw) || dev_alloc(&c.Wt3, (size_t)3 * nw)) return bail(1);
-            if (launch_split3(p->stream, c.W, c.W3, nw, nw) || launch_split3(p->stream, c.Wt, c.Wt3, nw, nw)) return bail(fail("operand split failed"));
         }
         if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
         hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));
@@ -2330,45 +2241,37 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
     g.A0 = dA; g.lda = K; g.B0 = dB; g.ldb = N; g.C = dC; g.ldc = N;
     g.M = M; g.N = N; g.K = K; g.splitK = sk; g.sCsplit = (long)M * N;
     int rc;
-    const char *mode = getenv("SURFH_SELFTEST_BF16X3");
+    const char *mode = getenv("SURFH_SELFTEST_F16X2");
     if (mode && mode[0] == '1') {
-        // NT form: B is handed over as [K][N]; transpose it on the host into [N][K]
+        // two-piece fp16 kernel, NT form: B is handed over as [K][N]; transpose it on the host into [N][K]
         std::vector<float> bt((size_t)N * K);
         for (int k = 0; k < K; ++k)
             for (int n = 0; n < N; ++n) bt[(size_t)n * K + k] = B[(size_t)k * N + n];
         HIP_OK(hipMemcpy(dB, bt.data(), bt.size() * 4, hipMemcpyHostToDevice));
         g.ldb = K;
-        if (mode[1] == 'h' || mode[1] == 'c') {            // "1h": two-piece fp16 producer/consumer kernel, "1c": all-consumer kernel
-            unsigned short *dB16 = nullptr;
-            unsigned *dmax = nullptr;
-            float amB = 0.f;
-            for (float v : bt) amB = std::max(amB, std::fabs(v));
-            std::vector<unsigned> rows((size_t)M, 0u);           // max |A[m][:]| as bit patterns
-            for (int m = 0; m < M; ++m) {
-                float am = 0.f;
-                for (int k = 0; k < K; ++k) am = std::max(am, std::fabs(A[(size_t)m * K + k]));
-                memcpy(&rows[m], &am, 4);
-            }
-            HIP_OK(hipMalloc((void **)&dB16, bt.size() * 4));
-            HIP_OK(hipMalloc((void **)&dmax, rows.size() * sizeof(unsigned)));
-            HIP_OK(hipMemcpy(dmax, rows.data(), rows.size() * sizeof(unsigned), hipMemcpyHostToDevice));
-            g.sB16 = gemm_f16x2_scale(amB); g.B16 = dB16; g.pB16 = (long)bt.size(); g.amax = dmax;
-            rc = launch_split2h(nullptr, dB, dB16, (long)bt.size(), (long)bt.size(), g.sB16);
-            unsigned short *dA16 = nullptr;
-            if (rc == 0 && mode[1] == 'c') {
-                HIP_OK(hipMalloc((void **)&dA16, (size_t)M * K * 4));
-                rc = launch_split_rows2h(nullptr, dA, dmax, dA16, M, K, (long)M * K);
-                g.A3 = dA16; g.pA3 = (long)M * K;
-                if (rc == 0) rc = launch_gemm_nt_f16x2_cc(nullptr, g);
-            } else if (rc == 0) {
-                rc = launch_gemm_nt_f16x2_pc(nullptr, g);
-            }
-            if (rc == 0) rc = (int)hipDeviceSynchronize();
-            hipFree(dB16);
-            hipFree(dmax);
-            hipFree(dA16);
-        } else
-        rc = (mode[1] == 'p') ? launch_gemm_nt_bf16x3_pc(nullptr, g) : launch_gemm_nt_bf16x3(nullptr, g);   // "1p": producer/consumer kernel
+        unsigned short *dB16 = nullptr, *dA16 = nullptr;
+        unsigned *dmax = nullptr;
+        float amB = 0.f;
+        for (float v : bt) amB = std::max(amB, std::fabs(v));
+        std::vector<unsigned> rows((size_t)M, 0u);           // max |A[m][:]| as bit patterns
+        for (int m = 0; m < M; ++m) {
+            float am = 0.f;
+            for (int k = 0; k < K; ++k) am = std::max(am, std::fabs(A[(size_t)m * K + k]));
+            memcpy(&rows[m], &am, 4);
+        }
+        HIP_OK(hipMalloc((void **)&dB16, bt.size() * 4));
+        HIP_OK(hipMalloc((void **)&dmax, rows.size() * sizeof(unsigned)));
+        HIP_OK(hipMalloc((void **)&dA16, (size_t)M * K * 4));
+        HIP_OK(hipMemcpy(dmax, rows.data(), rows.size() * sizeof(unsigned), hipMemcpyHostToDevice));
+        g.sB16 = gemm_f16x2_scale(amB); g.B16 = dB16; g.pB16 = (long)bt.size(); g.amax = dmax;
+        rc = launch_split2h(nullptr, dB, dB16, (long)bt.size(), (long)bt.size(), g.sB16);
+        if (rc == 0) rc = launch_split_rows2h(nullptr, dA, dmax, dA16, M, K, (long)M * K);
+        g.A3 = dA16; g.pA3 = (long)M * K;
+        if (rc == 0) rc = launch_gemm_nt_f16x2_cc(nullptr, g);
+        if (rc == 0) rc = (int)hipDeviceSynchronize();
+        hipFree(dB16);
+        hipFree(dmax);
+        hipFree(dA16);
     } else {
         rc = launch_gemm_f32(nullptr, g);
     }

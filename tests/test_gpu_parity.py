@@ -47,58 +47,18 @@ def test_gemm_mfma_selftest():
         assert e < 2e-6, (M, N, K, sk, e)
 
 
-def test_gemm_split_bf16_selftest():
-    """Exact 3-way bf16 splitting on the bf16 matrix cores must be as accurate as the fp32 MFMA path."""
-    from surfh_amd import _lib
-    L = _lib.load()
-    rng = np.random.default_rng(1)
-    os.environ["SURFH_SELFTEST_BF16X3"] = "1"
-    try:
-        for (M, N, K, sk) in [(128, 128, 16, 1), (256, 128, 256, 1), (128, 384, 1024, 2)]:
-            A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, K)))).astype(np.float32)   # wide dynamic range
-            B = rng.standard_normal((K, N)).astype(np.float32) + np.arange(N, dtype=np.float32)[None, :] * 0.02
-            Cg = np.empty((M, N), dtype=np.float32)
-            _lib.check(L.surfh_gemm_selftest(0, M, N, K, sk, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
-            Cr = A.astype(np.float64) @ B.astype(np.float64)
-            e = rel(Cg, Cr)
-            note("gemm_bf16x3", M=M, N=N, K=K, sk=sk, err=e)
-            assert e < 5e-7, (M, N, K, sk, e)
-    finally:
-        os.environ.pop("SURFH_SELFTEST_BF16X3")
-
-
-def test_gemm_producer_consumer_selftest():
-    """The 8-wave producer/consumer form of the split-bf16 GEMM (gemm_pc3.hip): same accuracy, ragged last 256-column
-    tile, split K."""
-    from surfh_amd import _lib
-    L = _lib.load()
-    rng = np.random.default_rng(2)
-    os.environ["SURFH_SELFTEST_BF16X3"] = "1p"
-    try:
-        for (M, N, K, sk) in [(128, 128, 32, 1), (128, 256, 64, 1), (256, 384, 512, 2), (384, 640, 1056, 3)]:
-            A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, K)))).astype(np.float32)
-            B = rng.standard_normal((K, N)).astype(np.float32) + np.arange(N, dtype=np.float32)[None, :] * 0.02
-            Cg = np.empty((M, N), dtype=np.float32)
-            _lib.check(L.surfh_gemm_selftest(0, M, N, K, sk, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
-            e = rel(Cg, A.astype(np.float64) @ B.astype(np.float64))
-            note("gemm_bf16x3_pc", M=M, N=N, K=K, sk=sk, err=e)
-            assert e < 5e-7, (M, N, K, sk, e)
-    finally:
-        os.environ.pop("SURFH_SELFTEST_BF16X3")
-
-
-@pytest.mark.parametrize("kernel", ["1h", "1c"], ids=["producer_consumer", "all_consumer_256"])
-def test_gemm_two_piece_fp16_selftest(kernel):
-    """The two-piece fp16 GEMMs (gemm_pc16.hip; gemm_cc16.hip, the 256x256 all-consumer tile with both operands delivered
-    as pieces by LDS-DMA): power-of-two operand scales, round-to-nearest split, three products.  Same gate as the bf16 split; element magnitudes spread over 12 decades within the operand (entries far
+def test_gemm_two_piece_fp16_selftest():
+    """The two-piece fp16 GEMM (gemm_cc16.hip, the 256x256 all-consumer tile with both operands delivered as pieces by
+    LDS-DMA): power-of-two operand scales, round-to-nearest split, three products; ragged tiles, split K, K slabs of 1, 2
+    and 33 steps.  Element magnitudes spread over 12 decades within the operand (entries far
     below the operand's largest magnitude keep their absolute, not their relative, precision), an all-zero operand, and
     non-negative operands where a truncating split would show a bias."""
     from surfh_amd import _lib
     L = _lib.load()
     rng = np.random.default_rng(2)
-    os.environ["SURFH_SELFTEST_BF16X3"] = kernel
+    os.environ["SURFH_SELFTEST_F16X2"] = "1"
     try:
-        for (M, N, K, sk) in [(128, 128, 32, 1), (128, 256, 64, 1), (256, 384, 512, 2), (384, 640, 1056, 3), (1664, 1408, 2112, 2)]:
+        for (M, N, K, sk) in [(128, 128, 32, 1), (128, 256, 64, 1), (256, 384, 512, 2), (384, 640, 1056, 3), (64, 128, 96, 1), (1664, 1408, 2112, 2)]:
             A = (rng.standard_normal((M, K)) * np.exp(rng.uniform(-6, 6, (M, K)))).astype(np.float32)
             B = rng.standard_normal((K, N)).astype(np.float32) + np.arange(N, dtype=np.float32)[None, :] * 0.02
             for scale in (1.0, 1e20, 1e-20):
@@ -129,7 +89,7 @@ def test_gemm_two_piece_fp16_selftest(kernel):
         _lib.check(L.surfh_gemm_selftest(0, M, N, K, 1, _lib.fptr(Z), _lib.fptr(B), _lib.fptr(Cg)))
         assert not Cg.any()
     finally:
-        os.environ.pop("SURFH_SELFTEST_BF16X3")
+        os.environ.pop("SURFH_SELFTEST_F16X2")
 
 
 @pytest.fixture(scope="module")

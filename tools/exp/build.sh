@@ -1,15 +1,17 @@
 #!/bin/bash
-# builds the four experiment variants of the rx3 micro-benchmark (0 full, 1 no MFMA, 2 no data loads, 3 no stores)
+# builds the micro-benchmarks of tools/exp into _bin/ (git-ignored, travels to the GPU box)
 set -e
 cd "$(dirname "$0")"
 mkdir -p _bin
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _bin/rx3 ../../surfh_amd/csrc/dft_rx3.hip rx3_main.hip &
-for e in 0 1 2 3 4; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGX_EXP=$e -o _bin/gemm_exp$e gemm_exp.hip gemm_main.hip &
+C="hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value"
+$C -o _bin/rx3 ../../surfh_amd/csrc/dft_rx3.hip rx3_main.hip &
+$C -o _bin/h2 ../../surfh_amd/csrc/dft_h2.hip ../../surfh_amd/csrc/dft_rx3.hip h2_main.hip &
+$C -o _bin/cc_bench ../../surfh_amd/csrc/gemm_cc16.hip cc_main.hip &
+for e in 1 2 3 4 6; do      # the GEMM with one cost removed at a time (cc_main.hip)
+  $C -DCC_EXP=$e -o _bin/cc_exp$e ../../surfh_amd/csrc/gemm_cc16.hip cc_main.hip &
 done
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _bin/gemm_rx3 gemm_rx3.hip gemm_rx3_main.hip &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _bin/gemm_pc ../../surfh_amd/csrc/gemm_pc3.hip ../../surfh_amd/csrc/gemm_pc16.hip ../../surfh_amd/csrc/gemm_cc16.hip ../../surfh_amd/csrc/gemm_bf16x3.hip gemm_pc_main.hip &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -o _bin/gemm_bias ../../surfh_amd/csrc/gemm_pc3.hip ../../surfh_amd/csrc/gemm_bf16x3.hip ../../surfh_amd/csrc/gemm_f32.hip gemm_bias_main.hip &
-hipcc --offload-arch=gfx950 -O3 -o _bin/copy_bw copy_bw.hip &
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -DWPS=1 -DDEPTH=3 -o _bin/rx3v2 rx3v2.hip &
+$C -o _bin/copy_bw copy_bw.hip &
+$C -o _bin/stride_bw stride_bw.hip &
+$C -o _bin/mall_copy mall_copy.hip &
+$C -DWPS=1 -DDEPTH=3 -o _bin/rx3v2 rx3v2.hip &
 wait
