@@ -227,6 +227,8 @@ def main():
                 return "gemm_nt_f16x2_cc_kernel"
             if name.startswith("specmix_"):       # interleaved spectra where the two-piece fp16 passes run (dft_h2.hip)
                 return name + ("_ilv_kernel" if any(k.startswith("dft_h2_") for k in prof_all) else "_kernel")
+            if name.startswith("dft_h2_") and name.endswith("_adjmix"):
+                return "dft_h2_adjmix_kernel"      # the adjoint's last pass with the conj(OTF) product and the wavelength reduction fused in
             if name.startswith("dft_h2_"):
                 return "dft_h2_kernel"             # four template instances <KIND, MIX> of one kernel (dft_h2.hip)
             if name.startswith("dft_rx3_"):
@@ -236,8 +238,7 @@ def main():
             if name.startswith("dft_fold_rows"):
                 return "dft_fold_kernel"
             if name.startswith("spmm_"):
-                f16 = os.environ.get("SURFH_WBLUR_F16") != "0" and os.environ.get("SURFH_WBLUR_PC") != "0" and \
-                    os.environ.get("SURFH_WBLUR_FP32") != "1" and os.environ.get("SURFH_WBLUR_CC", "2") == "2"
+                f16 = os.environ.get("SURFH_WBLUR_FP32") != "1"
                 if name == "spmm_gather_fwd" and f16:
                     return "spmm_group_gather_f16_kernel" if os.environ.get("SURFH_GATHER_GROUPED") != "0" and \
                         os.environ.get("SURFH_GATHER_SORTED") != "0" else "spmm_rows_f16_kernel"
@@ -278,8 +279,8 @@ def main():
                 roof = {"bound": "mfma", "achieved": nprod * ach, "peak": peak, "unit": "TFLOP/s",
                         "frac": nprod * ach / peak, "traffic": traffic, "kernel": dom, "launches": cnt,
                         "avg_ms": ms / cnt, "algorithmic_fp32_tflops": ach,
-                        "note": "matrix-core flops actually issued (each fp32 product = 3 fp16 products of a two-piece split, 6 bf16 "
-                                "products with SURFH_WBLUR_F16=0) against the dense peak of that instruction"}
+                        "note": "matrix-core flops actually issued (each fp32 product = 3 fp16 products of a two-piece split) "
+                                "against the dense peak of that instruction"}
             else:
                 # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
                 # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel
@@ -304,17 +305,20 @@ def main():
             "stage_ms_note": f"per-stage HIP-event times from the {n_all} untimed warm-up step(s) with every stage bracketed; "
                              "the timed region brackets only the kernel group of `roofline`",
         }
-        # the HBM-bound half of the path, whichever kernel group dominates: the four DFT passes of a step against the
-        # algorithmic bytes of its two 2-D transforms (FFT-conv stage)
-        dft = [(k, v) for k, v in (groups if dom_prefix == "dft_" else groups_all).items() if k.startswith(("dft_rx3", "dft_fold", "dft_h2"))]
+        # the HBM-bound half of the path as a whole: everything a step spends on its two 2-D transforms, the OTF product and
+        # the wavelength reduction (the DFT passes, the fused adjoint tail or the separate reduction kernel) against the
+        # algorithmic bytes of the FFT-conv stage.  Per-stage times of the warm-up steps (every stage bracketed).
+        stage_keys = ("dft_rx3", "dft_fold", "dft_h2", "specmix_adj", "specmix_fwd")
+        dft = [(k, v) for k, v in groups_all.items() if k.startswith(stage_keys)]
         if dft:
             n_l = sum(v[0] for _, v in dft)
-            t_s = sum(v[1] for _, v in dft) * 1e-3
-            ach = 0.5 * Lown * (Nf * 8 + N * N * 4) * n_l / t_s / 1e9
+            t_step = sum(v[1] for _, v in dft) * 1e-3 / max(n_all, 1)
+            ach = 2.0 * Lown * (Nf * 8 + N * N * 4) / t_step / 1e9
             out["roofline_fft_conv_stage"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                               "frac": ach / HBM_PEAK_GBS, "kernel": "+".join(sorted(k for k, _ in dft)),
-                                              "launches": n_l, "avg_ms": t_s * 1e3 / n_l,
-                                              "traffic": pmc.get(dft[0][0], {}).get("hbm_bytes_per_launch")}
+                                              "launches_per_step": n_l / max(n_all, 1), "ms_per_step": t_step * 1e3,
+                                              "note": "whole stage: algorithmic bytes of a step's two 2-D transforms (OTF read once and "
+                                                      "cube written / read once per direction) over the time of every kernel of the stage"}
         # the matrix-core half of the path, whichever group dominates: R / R^T against the fp32-MFMA peak
         gm = [(k, v) for k, v in (groups if dom_prefix == "gemm_wblur" else groups_all).items() if k.startswith("gemm_nt")]
         if gm:
@@ -324,7 +328,7 @@ def main():
             flops_step = sum(2.0 * 2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width
                              for c in m.channels)
             ach = flops_step * steps_seen / t_s / 1e12
-            nprod = 3.0 if gm[0][0].startswith("gemm_nt_f16x2") else 6.0
+            nprod = 3.0
             out["roofline_spectral_blur_gemm"] = {"bound": "mfma", "achieved": nprod * ach, "peak": MFMA_16BIT_PEAK_TF, "unit": "TFLOP/s",
                                                   "frac": nprod * ach / MFMA_16BIT_PEAK_TF, "kernel": gm[0][0], "launches": n_l,
                                                   "avg_ms": t_s * 1e3 / n_l, "algorithmic_fp32_tflops": ach,

@@ -51,6 +51,21 @@ struct DftH2Args {
     int mix_l0 = 0;                            // with batch > 1 (a wavelength chunk, batched over kb): first plane of the chunk
 };
 
+// Fused tail of the adjoint: the kind-0 pass of rfft2 followed, inside the kernel, by
+//   madj[t][c][ka][kb] = sum_l tpl[t][l] (conj(H[ka][kb][l]) Y[ka][kb][l])[c]
+// (g: the kind-0 arguments with batch = k_beta, N = LP; g.dst / ldc / sC unused).  H interleaved complex like Y.
+struct DftH2AdjMix {
+    const float *hsrc = nullptr;               // sotf: row ka at pitch ldh floats, k_beta at stride sH floats, then [l][2]
+    long ldh = 0, sH = 0;
+    const float *tpl = nullptr;                // [T][LPt]
+    int T = 0, LPt = 0;
+    float *mpart = nullptr;                    // work buffer of dft_h2_adjmix_part_floats(LP, hb) floats
+    int nslot = 0;                             // set by the launcher
+};
+size_t dft_h2_adjmix_part_floats(long LP, int hb);
+int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjMix &am, float *madj, long PL, long KBP,
+                         const unsigned short *img, int kA);
+
 // host: builds the LDS image of the two row-major [MP][KP] fp32 matrices (MP <= 128, KP <= 128, KP % 16 == 0);
 // returns the scale exponent kA (pieces hold A * 2^kA)
 int dft_h2_build_image(const float *A0, const float *A1, int MP, int KP, int lda, unsigned short *img);

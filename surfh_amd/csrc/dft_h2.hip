@@ -329,6 +329,342 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// Adjoint tail, fused: the complex pass along alpha of rfft2 (kind 0) whose epilogue, instead of storing the spectrum
+// Y[ka][kb][l], forms conj(H) Y and reduces it over the wavelengths with the template weights -- the reference's
+// `sum_l tpl[t,l] conj(sotf) rfft2(cube)` (spectroModel.py:175-181) -- so the 1 GB spectrum is neither written nor read
+// back and `specmix_adj_kernel` disappears.
+//
+// The MFMA operands swap roles: the data fragments go in as A, the matrix fragments as B.  The fragment registers are the
+// same, but the accumulator then has lane = output row (k_alpha) and registers = the tile's 32 lane-columns, i.e. a
+// register quad is (re, im) of two adjacent wavelengths of ONE row: the product with conj(H) needs no cross-lane move and
+// the sum over wavelengths runs inside the lane.  A lane carries sum_l tpl[t][l] z[l] for its rows (4 templates x re/im x
+// (row r, row N-r) per row tile) across all tiles of one k_beta: 16 registers per row tile, so a wave takes 64 of the 128
+// output rows.  Workgroups come in pairs that transform the same columns, one per row half: a workgroup keeps only its 64
+// rows of the matrix image and has 96 KB of LDS for the OTF stream (below).  The block exponent is per tile (wave-uniform)
+// here, because an accumulator register no longer belongs to the lane that folded its column.
+// Partial sums leave the kernel once per (workgroup pair, k_beta) into `mpart[kb][slot][row][t][c]`; a second, tiny kernel
+// adds the slots in a fixed order (deterministic, no atomics).
+// Measured (config 3, 251 x 251 x 4096 planes): 0.59 ms against 0.42 + 0.42 ms for the pass and the separate reduction
+// (0.49 ms with the OTF replaced by a constant; 0.90 ms with the OTF read straight from memory, lane = row).
+__device__ __forceinline__ float wave_max(float m) {
+#define H2_DPPMAX(ctrl_) m = fmaxf(m, __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, m), ctrl_, 0xF, 0xF, false)))
+    H2_DPPMAX(0xB1);     // quad_perm [1,0,3,2]
+    H2_DPPMAX(0x4E);     // quad_perm [2,3,0,1]
+    H2_DPPMAX(0x141);    // row_half_mirror
+    H2_DPPMAX(0x140);    // row_mirror: every lane of a row of 16 holds the row's maximum
+#undef H2_DPPMAX
+    unsigned u = __float_as_uint(m);
+    auto s16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    m = fmaxf(m, fmaxf(__uint_as_float(s16[0]), __uint_as_float(s16[1])));
+    u = __float_as_uint(m);
+    auto s32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return fmaxf(m, fmaxf(__uint_as_float(s32[0]), __uint_as_float(s32[1])));
+}
+
+__global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, DftH2AdjMix am, const uint4 *__restrict__ img, int kA, int NS) {
+    static_assert(NWAVES == 8, "dft_h2_adjmix_kernel: 4 column streams x 2 row halves");
+    extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    constexpr int KIND = 0;
+    constexpr bool MIX = false;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Workgroups come in pairs that transform the same columns, one per half of the output rows (blockIdx b and b + 8: the
+    // same XCD under round-robin placement, so the second read of a tile comes from that XCD's L2 -- speed only).  A
+    // workgroup therefore keeps only its 64 rows of the matrix image (64 KB) and has 96 KB of LDS left for the OTF stream.
+    const int cs = wave;                                       // column stream
+    const int rh = ((int)blockIdx.x >> 3) & 1;                 // row half
+    const int vb = ((int)blockIdx.x >> 4) * 8 + ((int)blockIdx.x & 7), VP = (int)gridDim.x / 2;   // pair index, number of pairs
+    const int l31 = lane & 31, h = lane >> 5;
+    constexpr int TNW = 16, SRC_T = 32;
+    const int lcol = l31 >> 1;
+    const int tilesX = g.N / TNW;
+    const unsigned ldb4 = (unsigned)(g.ldb * 4), ldh4 = (unsigned)(am.ldh * 4);
+    const unsigned c4 = (unsigned)l31 * 4u;
+    const int nk = g.KP / BK;
+    const int kin = g.Kn / 2 + 1;
+    // unused by this kernel, referenced by the shared macros
+    const float4 *mtab = nullptr;
+    const float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float sgv = 0.f;
+    (void)mtab; (void)tw; (void)sgv; (void)lcol;
+    {   // this half's 64 rows of every (matrix, piece, k-step) block of the image
+        uint4 *l4 = reinterpret_cast<uint4 *>(lds);
+        for (int i = tid; i < IMG_HALFS / 16; i += NTHREADS) {
+            const int blk = i >> 7, in = i & 127;              // 128 uint4 (64 rows x 16 halfs) per block of the half image
+            l4[i] = img[blk * 256 + rh * 128 + in];
+        }
+    }
+    // super-tiles of 8 tiles (128 complex columns); wave cs takes tile 8 s + cs
+    const int s0 = (int)((long)NS * vb / VP), s1 = (int)((long)NS * (vb + 1) / VP);
+    const int ntw = s1 - s0;
+    __syncthreads();
+    if (ntw <= 0) return;
+
+    __amdgpu_buffer_rsrc_t R0;
+    int hv = h;
+    float xr[8], qr[8];
+    float x0[8], x1[8];
+    f16x8 c0h, c0l, c1h, c1l;
+    f32x16 acc1[2], acc2[2];
+    f32x2 M[2][2][4];                  // [row tile][row r / row N - r][template] (re, im)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) M[i][k][t] = f32x2{0.f, 0.f};
+
+    // fragments of the matrix rows of this wave's half: B operand now (same registers as the A fragment of dft_h2_kernel)
+#define H2_MFMA_SW(m_, kt_, acc_, bh_, bl_)                                                                     \
+    {                                                                                                           \
+        const unsigned short *ra = lds + ((m_) * 2 * KT + (kt_)) * (PIECE / 2) + l31 * RS + 8 * (h ^ ((l31 >> 3) & 1)); \
+        _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) {                                                      \
+            const unsigned short *p = ra + mt * 32 * RS;                                                        \
+            const f16x8 ah = *reinterpret_cast<const f16x8 *>(p);                                               \
+            const f16x8 al = *reinterpret_cast<const f16x8 *>(p + KT * (PIECE / 2));                            \
+            f32x16 c_ = acc_[mt];                                                                               \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl_, ah, c_, 0, 0, 0);                                  \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, al, c_, 0, 0, 0);                                  \
+            c_ = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh_, ah, c_, 0, 0, 0);                                  \
+            acc_[mt] = c_;                                                                                      \
+        }                                                                                                       \
+    }
+    // exponent of the tile's largest folded magnitude (wave-uniform)
+#define H2_MAXEXP_W(p_)                                                                                         \
+    {                                                                                                           \
+        float m_ = 0.f;                                                                                         \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) m_ = fmaxf(m_, fmaxf(fabsf(x0[j]), fabsf(x1[j])));        \
+        m_ = wave_max(m_);                                                                                      \
+        p_ = __builtin_amdgcn_readfirstlane(__builtin_amdgcn_frexp_expf(m_));                                   \
+    }
+    // partial sums of one k_beta leave the wave: the two lane halves (different wavelengths of the same rows) are added,
+    // lanes 0-31 store [row][t][c]
+#define H2_FLUSH(kb_)                                                                                           \
+    {                                                                                                           \
+        const long spk = tilesX / 8;                   /* super-tiles per k_beta */                              \
+        int bf = vb;                                                                                            \
+        while (bf > 0 && (long)NS * bf / VP > (long)(kb_) * spk) --bf;            /* first pair that holds tiles of kb */ \
+        const int slot = (vb - bf) * 8 + cs;                                                                    \
+        float *mp = am.mpart + ((long)(kb_) * am.nslot + slot) * (256 * 8);                                     \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
+            _Pragma("unroll") for (int k = 0; k < 2; ++k) {                                                     \
+                float v[8];                                                                                     \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                 \
+                    _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                             \
+                        const unsigned u = __float_as_uint(M[i][k][t][c]);                                      \
+                        const auto sw_ = __builtin_amdgcn_permlane32_swap(u, u, false, false);                  \
+                        v[2 * t + c] = __uint_as_float(sw_[0]) + __uint_as_float(sw_[1]);   /* lower half + upper half, in every lane */ \
+                    }                                                                                           \
+                    M[i][k][t] = f32x2{0.f, 0.f};                                                               \
+                }                                                                                               \
+                const int r = (2 * rh + i) * 32 + l31;                                                          \
+                const int row = k ? g.Rn - r : r;                                                               \
+                const bool ok_ = k ? (r >= 1 && r < g.rvalid && 2 * r != g.Rn) : (r < g.rvalid);                \
+                if (h == 0 && slot < am.nslot && ok_) {                                                         \
+                    *reinterpret_cast<float4 *>(mp + row * 8) = make_float4(v[0], v[1], v[2], v[3]);            \
+                    *reinterpret_cast<float4 *>(mp + row * 8 + 4) = make_float4(v[4], v[5], v[6], v[7]);        \
+                }                                                                                               \
+            }                                                                                                   \
+    }
+
+    int tile = 8 * s0 + cs;
+    const int tend = tile + 8 * ntw;
+    int e = 0, en = 0;
+
+    H2_LSETUP(tile);
+    H2_LOAD(0);
+    H2_FOLD(0);
+    {
+        int p;
+        H2_MAXEXP_W(p);
+        e = E_TARGET - p;
+    }
+    split8h(x0, e, c0h, c0l);
+    split8h(x1, e, c1h, c1l);
+    H2_LOAD(1);
+    // ---- the OTF stream -----------------------------------------------------------------------------------------
+    // The OTF rows of a tile reach the lanes through staging buffers in LDS: three 4 KB slots per wave.  A lane owns ROWS
+    // here, so read straight from memory a wave instruction would touch 32 rows x 32 B (measured: 2.3 TB/s).  Instead one
+    // block = 32 rows x 128 B (the tile's 16 wavelengths, re / im) is moved by four LDS-DMA instructions that each read 8
+    // whole 128-byte rows, into an XOR-swizzled [row][8 chunks of 16 B] image (chunk c of row k at position c ^ (k >> 1 & 7):
+    // conflict-free ds_read_b128 for the lane = row pattern), and read back as four 16-byte chunks per lane.  A tile has four
+    // blocks per wave (row tiles 0 / 1, rows r / N - r).  Blocks 0, 1, 2 are requested in k-steps 1, 2, 3 of the tile's own
+    // k loop, in front of that step's data loads: when the loop ends they have landed (vmcnt is one in-order counter and
+    // every fold waits for younger loads).  Block 3 follows into slot 0 as soon as block 0 has been read.
+    typedef float f32x4_ __attribute__((ext_vector_type(4)));
+    const unsigned hb_lds = (unsigned)(size_t)lds + (unsigned)IMG_HALFS + (unsigned)wave * 12288u;     // behind the 64 KB half image
+    // DMA lane map: instruction i moves LDS rows 8 i .. 8 i + 7; lane -> (row 8 i + (lane >> 3), position lane & 7), which
+    // holds chunk (lane & 7) ^ ((row >> 1) & 7) of that row; LDS row k = matrix row R0 + k (ascending) or R0 + 31 - k.
+    // (row >> 1) & 7 = (4 i + (lane >> 4)) & 7: two lane offsets per direction (i even / odd), the rest is in the scalar base
+    const unsigned hc0 = (unsigned)((lane & 7) ^ ((lane >> 4) & 3)), hc1 = hc0 ^ 4u;
+    const unsigned hoa0 = (unsigned)(lane >> 3) * ldh4 + hc0 * 16u, hoa1 = (unsigned)(lane >> 3) * ldh4 + hc1 * 16u;
+    const unsigned hod0 = (unsigned)(7 - (lane >> 3)) * ldh4 + hc0 * 16u, hod1 = (unsigned)(7 - (lane >> 3)) * ldh4 + hc1 * 16u;
+    const unsigned hrd = hb_lds + (unsigned)l31 * 128u, hsw = (unsigned)((l31 >> 1) & 7);
+    // request block blk_ (2 * row tile + (0: rows r, 1: rows N - r)) of the tile (kb_, first column n0_) into slot slot_
+#define H2_HDMA(blk_, slot_, kb_, n0_)                                                                          \
+    {                                                                                                           \
+        const int mt = 2 * rh + ((blk_) >> 1);                                                                  \
+        const bool dsc = ((blk_) & 1) != 0;                                                                     \
+        const char *hp = reinterpret_cast<const char *>(am.hsrc + (long)(kb_) * am.sH + (n0_) * 2);             \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                         \
+            /* ascending: rows mt*32 + 8 i + (lane >> 3); descending: rows Rn - mt*32 - 8 i - (lane >> 3) = base + 7 - (lane >> 3) */ \
+            const long r0 = dsc ? (long)(g.Rn - mt * 32 - 8 * i - 7) : (long)(mt * 32 + 8 * i);                 \
+            unsigned off = dsc ? ((i & 1) ? hod1 : hod0) : ((i & 1) ? hoa1 : hoa0);                             \
+            /* row Rn itself (the "mirror" of row 0, never used) may lie behind the array: its lanes read row Rn - 1 */ \
+            if (dsc && mt == 0 && i == 0 && (lane >> 3) == 0) off -= ldh4;                                      \
+            const char *bp = hp + r0 * (long)ldh4;                                                              \
+            const unsigned la = hb_lds + (unsigned)(slot_) * 4096u + (unsigned)i * 1024u;                       \
+            if (!(H2_EXP & 16))                                                                                 \
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(bp), "s"(la) : "memory"); \
+        }                                                                                                       \
+    }
+    // consume the block in slot slot_: mir_ 0 rows r / 1 rows N - r of row tile i_
+#define H2_HBLOCK(i_, mir_, slot_)                                                                              \
+    {                                                                                                           \
+        f32x4_ hq4[4];                                                                                          \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+            const unsigned ad = hrd + (unsigned)(slot_) * 4096u + (((unsigned)(2 * q + h)) ^ hsw) * 16u;        \
+            if (H2_EXP & 16) hq4[q] = f32x4_{1.f, 0.5f, 0.25f, 2.f};                                            \
+            else asm volatile("ds_read_b128 %0, %1" : "=v"(hq4[q]) : "v"(ad) : "memory");                       \
+        }                                                                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hq4[0]), "+v"(hq4[1]), "+v"(hq4[2]), "+v"(hq4[3])::"memory"); \
+        const float c0 = f * ((mir_) ? g.e[2] : g.e[0]), c1 = f * ((mir_) ? g.e[3] : g.e[1]);                   \
+        const float d0 = f * ((mir_) ? g.e_alt[2] : g.e_alt[0]), d1 = f * ((mir_) ? g.e_alt[3] : g.e_alt[1]);   \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                         \
+            float ta[4], tb[4];      /* template weights of this lane's two wavelengths of the quad: columns 4 q + 2 h, + 1 */ \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                                     \
+                const float lo0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q) * 4 + t));     \
+                const float lo1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q + 1) * 4 + t)); \
+                const float hi0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q + 2) * 4 + t)); \
+                const float hi1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, tv), (4 * q + 3) * 4 + t)); \
+                ta[t] = h ? hi0 : lo0;                                                                          \
+                tb[t] = h ? hi1 : lo1;                                                                          \
+            }                                                                                                   \
+            const float p0 = acc1[i_][4 * q], p1 = acc1[i_][4 * q + 1], p2 = acc1[i_][4 * q + 2], p3 = acc1[i_][4 * q + 3];   \
+            const float s0v = acc2[i_][4 * q], s1v = acc2[i_][4 * q + 1], s2v = acc2[i_][4 * q + 2], s3v = acc2[i_][4 * q + 3]; \
+            const float yr0 = c0 * p0 + c1 * s0v, yi0 = d0 * p1 + d1 * s1v, yr1 = c0 * p2 + c1 * s2v, yi1 = d0 * p3 + d1 * s3v; \
+            const f32x4_ hh = hq4[q];                                                                           \
+            const f32x2 z0 = {hh[0] * yr0 + hh[1] * yi0, hh[0] * yi0 - hh[1] * yr0};                            \
+            const f32x2 z1 = {hh[2] * yr1 + hh[3] * yi1, hh[2] * yi1 - hh[3] * yr1};                            \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) M[i_][mir_][t] += ta[t] * z0 + tb[t] * z1;            \
+        }                                                                                                       \
+    }
+    const bool piped = nk >= 5;        // k-steps 1 .. 3 of the loop below exist
+    while (true) {
+        asm volatile("" : "+v"(hv));
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
+        const int next = tile + 8;
+        const bool more = next < tend;
+        const int kb = tile / tilesX;
+        const long n0 = (long)(tile % tilesX) * TNW;
+        for (int kt = 0; kt + 1 < nk; ++kt) {
+            H2_MFMA_SW(0, kt, acc1, c0h, c0l);
+            H2_FOLD(kt + 1);
+            int p;
+            H2_MAXEXP_W(p);
+            en = (p + e > E_LIMIT) ? E_TARGET - p : e;
+            const int d = en - e;
+            if (piped) {               // wave-uniform; the slots were emptied by the previous tile's epilogue
+                if (kt == 1) { H2_HDMA(0, 0, kb, n0); }
+                else if (kt == 2) { H2_HDMA(1, 1, kb, n0); }
+                else if (kt == 3) { H2_HDMA(2, 2, kb, n0); }
+            }
+            if (kt + 2 < nk) {
+                H2_LOAD(kt + 2);
+            } else if (more) {
+                H2_LSETUP(next);
+                H2_LOAD(0);
+            }
+            split8h(x0, en, c0h, c0l);
+            H2_MFMA_SW(1, kt, acc2, c1h, c1l);
+            split8h(x1, en, c1h, c1l);
+            if (d != 0) {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        acc1[mt][r] = __builtin_amdgcn_ldexpf(acc1[mt][r], d);
+                        acc2[mt][r] = __builtin_amdgcn_ldexpf(acc2[mt][r], d);
+                    }
+            }
+            e = en;
+        }
+        H2_MFMA_SW(0, nk - 1, acc1, c0h, c0l);
+        if (more) {
+            H2_FOLD(0);
+            int p;
+            H2_MAXEXP_W(p);
+            en = E_TARGET - p;
+            H2_LOAD(1);
+            split8h(x0, en, c0h, c0l);
+        }
+        H2_MFMA_SW(1, nk - 1, acc2, c1h, c1l);
+        if (more) split8h(x1, en, c1h, c1l);
+        {
+            // epilogue: z = conj(H) Y for this lane's rows, summed over the tile's wavelengths with the template weights.
+            // lane L of `tv` holds tpl[t = L & 3][column n0 + (L >> 2)]; read back lane by lane (scalar)
+            const float tv = ((lane & 3) < am.T) ? am.tpl[(long)(lane & 3) * am.LPt + n0 + (lane >> 2)] : 0.f;
+            const float f = __builtin_amdgcn_ldexpf(1.f, -e - kA);
+            if (!piped) {
+                H2_HDMA(0, 0, kb, n0); H2_HDMA(1, 1, kb, n0); H2_HDMA(2, 2, kb, n0);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            H2_HBLOCK(0, 0, 0);
+            H2_HDMA(3, 0, kb, n0);
+            H2_HBLOCK(0, 1, 1);
+            H2_HBLOCK(1, 0, 2);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            H2_HBLOCK(1, 1, 0);
+        }
+        if (!more || next / tilesX != kb) H2_FLUSH(kb);
+        if (!more) break;
+        e = en;
+        tile = next;
+    }
+#undef H2_HDMA
+#undef H2_HBLOCK
+#undef H2_MFMA_SW
+#undef H2_MAXEXP_W
+#undef H2_FLUSH
+}
+
+// madj[t][c][ka * KBP + kb] = sum over the slots that hold partial sums of kb (fixed order); the padding of the spectrum
+// planes (kb >= hb, ka >= Na) is written as zero, as the separate reduction leaves it
+__global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *__restrict__ mpart, float *__restrict__ madj, int nslot,
+                                                                   int T, int Na, int KAP, int hb, long KBP, long PL, int NS, int G, int spk) {
+    const int kb = blockIdx.x;
+    if (kb >= hb) {
+        for (int i = threadIdx.x; i < KAP * 8; i += 256) {
+            const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
+            if (t < T) madj[((long)t * 2 + c) * PL + (long)row * KBP + kb] = 0.f;
+        }
+        return;
+    }
+    int bf = 0, bl = G - 1;      // pairs bf .. bl of the pass hold tiles of kb: range of pair b = [NS b / G, NS (b + 1) / G)
+    {
+        const long lo = (long)kb * spk, hi = lo + spk;
+        int b = (int)(((long)lo * G) / NS);
+        while (b > 0 && (long)NS * b / G > lo) --b;
+        while ((long)NS * (b + 1) / G <= lo) ++b;
+        bf = b;
+        while (b + 1 < G && (long)NS * (b + 1) / G < hi) ++b;
+        bl = b;
+    }
+    const int ns = (bl - bf + 1) * 8 < nslot ? (bl - bf + 1) * 8 : nslot;
+    for (int i = threadIdx.x; i < KAP * 8; i += 256) {
+        const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
+        if (t >= T) continue;
+        float s = 0.f;
+        if (row < Na)
+            for (int sl = 0; sl < ns; ++sl) s += mpart[((long)kb * nslot + sl) * (256 * 8) + row * 8 + tc];
+        madj[((long)t * 2 + c) * PL + (long)row * KBP + kb] = s;
+    }
+}
+
 #undef H2_MIXTAB
 #undef H2_FSETUP
 #undef H2_LSETUP
@@ -407,6 +743,49 @@ int launch_dft_h2(hipStream_t stream, const DftH2Args &g, const unsigned short *
         if (int e = ensure_dynamic_lds(dft_h2_kernel<2, false>, LDS_IMG, d2)) return e;
         hipLaunchKernelGGL((dft_h2_kernel<2, false>), grid, dim3(NTHREADS), LDS_IMG, stream, g, im, kA, (int)NS, NT);
     }
+    return (int)hipGetLastError();
+}
+
+// workgroups of the fused adjoint pass and partial-sum slots per k_beta for `tiles_per_kb` = LP / 16 tiles per k_beta
+static void adjmix_geometry(int dev_cus, long tilesX, int hb, long &NS, int &G, int &nslot) {
+    NS = tilesX / 8 * hb;                                      // super-tiles of 8 tiles
+    long pairs = dev_cus / 16 * 8;                             // workgroup pairs (b, b + 8): the grid is a multiple of 16
+    if (pairs < 8) pairs = 8;
+    while (pairs > 8 && pairs > NS) pairs -= 8;
+    G = (int)(2 * pairs);
+    const long spk = tilesX / 8;
+    const long per = NS / pairs > 0 ? NS / pairs : 1;          // smallest range of a pair (super-tiles)
+    nslot = (int)(8 * ((spk + per - 1) / per + 2));
+}
+
+size_t dft_h2_adjmix_part_floats(long LP, int hb) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
+    long NS; int G, nslot;
+    adjmix_geometry(cus, LP / 16, hb, NS, G, nslot);
+    return (size_t)hb * nslot * 256 * 8;
+}
+
+int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjMix &am0, float *madj, long PL, long KBP, const unsigned short *img, int kA) {
+    if (g.kind != 0 || g.mhat || g.KP % BK || g.KP < 2 * BK || g.KP > KT * BK || g.KP > g.Kn || g.N % 128 || g.batch < 1 || !img || !g.src ||
+        !am0.hsrc || !am0.tpl || !am0.mpart || !madj || am0.T < 1 || am0.T > 4 || g.Rn < 32 * 3 + 31 || g.Rn > 255 || g.rvalid < 1 || g.rvalid > 128)
+        return (int)hipErrorInvalidValue;
+    const double rows_src = (double)g.Kn + 9.0;
+    if (rows_src * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0 || 260.0 * (double)am0.ldh * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return (int)hipErrorInvalidDevice;
+    long NS; int G, nslot;
+    adjmix_geometry(cus, g.N / 16, g.batch, NS, G, nslot);
+    if (NS >= 2147483647L / 8 || g.N % 128) return (int)hipErrorInvalidValue;
+    DftH2AdjMix am = am0;
+    am.nslot = nslot;
+    static unsigned long long d4 = 0;
+    const size_t ldsb = LDS_IMG / 2 + (size_t)NWAVES * 12288;  // half image + three 4 KB OTF staging slots per wave = 160 KB
+    if (int e = ensure_dynamic_lds(dft_h2_adjmix_kernel, ldsb, d4)) return e;
+    hipLaunchKernelGGL(dft_h2_adjmix_kernel, dim3((unsigned)G), dim3(NTHREADS), ldsb, stream, g, am, reinterpret_cast<const uint4 *>(img), kA, (int)NS);
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dft_h2_adjmix_reduce_kernel, dim3((unsigned)KBP), dim3(256), 0, stream, am.mpart, madj, nslot, am.T, g.Rn, (int)(PL / KBP),
+                       g.batch, KBP, PL, (int)NS, G / 2, (int)(g.N / 16 / 8));
     return (int)hipGetLastError();
 }
 

@@ -157,6 +157,7 @@ struct surfh_plan {
     // mhat when T == 0) are then INTERLEAVED [..][LP][2] instead of planar [2][..][LP]
     bool h2 = false;
     unsigned short *h2img = nullptr;             // three images: (Cma, Sma), (Gc, Gs), (Cf, Sf)
+    float *adjmix_part = nullptr;                // fused adjoint tail (dft_h2_adjmix_kernel): partial sums per (k_beta, slot); null: off
     int h2kA[3] = {0, 0, 0};
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
@@ -799,7 +800,9 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
 
 // ---- two-piece fp16 passes, matrices resident in LDS, interleaved complex arrays (dft_h2.h) --------
 // cube [NBP][NAP][LP] -> spec [KAP][KBP][LP][2]        (tmp ycol viewed as Z[KBP][NAP][LP][2])
-int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst) {
+// `madj` != nullptr: the second pass does not store the spectrum but multiplies it by conj(sotf) and reduces it over the
+// wavelengths with the template weights straight into madj [T][2][KAP][KBP] (the adjoint's tail, spectroModel.py:175-181)
+int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = nullptr) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
     DftH2Args g;   // r2c along beta
@@ -816,6 +819,13 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst) {
     h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
     h.e[0] = 1.f; h.e[1] = 1.f; h.e[2] = 1.f; h.e[3] = -1.f;                 // Re Z[r] = C ae + S bo, Re Z[N-r] = C ae - S bo
     h.e_alt[0] = 1.f; h.e_alt[1] = -1.f; h.e_alt[2] = 1.f; h.e_alt[3] = 1.f;  // Im Z[r] = C be - S ao, Im Z[N-r] = C be + S ao
+    if (madj) {
+        DftH2AdjMix am;
+        am.hsrc = p->sotf; am.ldh = 2 * p->KBP * LP; am.sH = 2 * LP; am.tpl = p->tpl; am.T = p->T; am.LPt = (int)LP; am.mpart = p->adjmix_part;
+        Prof pr(p, "dft_h2_cols_fwd_adjmix");
+        LAUNCH_OK(launch_dft_h2_adjmix(p->stream, h, am, madj, p->PL, p->KBP, p->h2img, p->h2kA[0]));
+        return 0;
+    }
     {
         Prof pr(p, "dft_h2_cols_fwd");
         LAUNCH_OK(launch_dft_h2(p->stream, h, p->h2img, p->h2kA[0]));
@@ -910,6 +920,15 @@ int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = fals
 // ---------------------------------------------------------------------------------------------
 int rfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? rfft2_lam(p, src, dst) : rfft2_lam_fold(p, src, dst); }
 int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false) { return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_fold(p, src, dst, mix); }
+
+// mhat[t] = sum_l tpl[t][l] conj(sotf[l]) rfft2(cube[l])  (T > 0), or the per-plane product (T == 0)
+int adjoint_tail(surfh_plan *p, const float *cube) {
+    if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->mhat);
+    if (rfft2_cube(p, cube, p->spec)) return 1;
+    Prof pr(p, "specmix_adj");
+    LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->h2));
+    return 0;
+}
 
 int forward_dev(surfh_plan *p, const float *x, float *y) {
     hipStream_t s = p->stream;
@@ -1049,11 +1068,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
                 LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, acc, c.nlam, 1));
         }
     }
-    if (rfft2_cube(p, acc, p->spec)) return 1;
-    {
-        Prof pr(p, "specmix_adj");
-        LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->h2));
-    }
+    if (adjoint_tail(p, acc)) return 1;
     if (p->T > 0) {
         if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
         Prof pr(p, "unpad_planes");
@@ -1126,6 +1141,7 @@ int surfh_plan_destroy(surfh_plan *p) {
         hipFree(v);
     hipFree(p->dft3);
     hipFree(p->h2img);
+    hipFree(p->adjmix_part);
     hipFree(p->dscal);
     hipFree(p->dscratch);
     hipFree(p->cg_hist);
@@ -1342,6 +1358,13 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             p->h2kA[1] = dft_h2_build_image(Gc.data(), Gs.data(), p->MPb, p->KPb, p->KPb, im.data() + DFT_H2_IMAGE_HALFS);
             p->h2kA[2] = dft_h2_build_image(Cf.data(), Sf.data(), p->MPb, p->KPb, p->KPb, im.data() + 2 * DFT_H2_IMAGE_HALFS);
             if (dev_upload(&p->h2img, im)) return bail(1);
+            // fused adjoint tail: the last pass of rfft2 multiplies by conj(sotf) and reduces over the wavelengths itself
+            // (needs T <= 4 templates and 127 <= Na <= 255 output rows; SURFH_ADJ_FUSED=0: separate pass + reduction)
+            const char *eaf = getenv("SURFH_ADJ_FUSED");
+            if (!(eaf && eaf[0] == '0') && p->T >= 1 && p->T <= 4 && p->Na >= 127 && p->Na <= 255 && p->LP % 128 == 0) {
+                const size_t npart = dft_h2_adjmix_part_floats(p->LP, p->Nb / 2 + 1);
+                if (npart && dev_alloc(&p->adjmix_part, npart)) return bail(1);
+            }
         }
         const char *e5 = getenv("SURFH_DFT_RX3");
         p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
@@ -1591,8 +1614,7 @@ int surfh_wct_adjoint(surfh_plan *p, const float *cube, float *maps) {
     HIP_OK(hipMemcpyAsync(p->io_cube, cube, (size_t)p->Lc * p->Na * p->Nb * sizeof(float), hipMemcpyHostToDevice, s));
     LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
     LAUNCH_OK(launch_cube_to_lam_inner(s, p->io_cube, p->cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP));
-    if (rfft2_cube(p, p->cube, p->spec)) return 1;
-    LAUNCH_OK(launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, false, p->h2));
+    if (adjoint_tail(p, p->cube)) return 1;
     if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
     LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, p->io_x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     HIP_OK(hipMemcpyAsync(maps, p->io_x, p->isize * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -1646,9 +1668,8 @@ int surfh_wct_expsol(surfh_plan *p, const float *cube, const double *mu_reg, con
     int rc = launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP);
     if (!rc) rc = launch_cube_to_lam_inner(s, p->io_cube, p->cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP);
     if (rc) return done(fail("launch failed: %s", hipGetErrorString((hipError_t)rc)));
-    if (rfft2_cube(p, p->cube, p->spec)) return done(1);
-    rc = launch_specmix_adj(s, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, false, p->h2);
-    if (!rc) rc = launch_wct_solve(s, p->hth, dreg, dmu, p->mhat, p->mhat2, p->T, p->PL, dflag);
+    if (adjoint_tail(p, p->cube)) return done(1);
+    rc = launch_wct_solve(s, p->hth, dreg, dmu, p->mhat, p->mhat2, p->T, p->PL, dflag);
     if (rc) return done(fail("launch failed: %s", hipGetErrorString((hipError_t)rc)));
     if (irfft2_planes(p, p->mhat2, p->maps_pad, p->T)) return done(1);
     rc = launch_unpad_planes(s, p->maps_pad, p->io_x, p->T, p->Na, p->Nb, p->NAP, p->NBP);

@@ -5,7 +5,7 @@ cd "$(dirname "$0")"
 mkdir -p _bin
 C="hipcc --offload-arch=gfx950 -O3 -std=c++17 -Wno-unused-value"
 $C -o _bin/rx3 ../../surfh_amd/csrc/dft_rx3.hip rx3_main.hip &
-$C -o _bin/h2 ../../surfh_amd/csrc/dft_h2.hip ../../surfh_amd/csrc/dft_rx3.hip h2_main.hip &
+$C -o _bin/h2 ../../surfh_amd/csrc/dft_h2.hip ../../surfh_amd/csrc/dft_rx3.hip h2_main.hip &      # all four passes + the fused adjoint tail
 $C -o _bin/cc_bench ../../surfh_amd/csrc/gemm_cc16.hip cc_main.hip &
 for e in 1 2 3 4 6; do      # the GEMM with one cost removed at a time (cc_main.hip)
   $C -DCC_EXP=$e -o _bin/cc_exp$e ../../surfh_amd/csrc/gemm_cc16.hip cc_main.hip &

@@ -9,11 +9,7 @@
 #include <cmath>
 #include <vector>
 #include "../../surfh_amd/csrc/dft_rx3.h"
-#ifdef WITH_ADJMIX
-#include "dft_h2_adjmix.h"
-#else
 #include "../../surfh_amd/csrc/dft_h2.h"
-#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void fill_k(float *p, long n, unsigned seed, int mode, long pitch) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -240,7 +236,7 @@ int main(int argc, char **argv) {
             CK(hipFree(yb[0])); CK(hipFree(yb[1]));
         }
     }
-#ifdef WITH_ADJMIX
+#ifndef NO_ADJMIX
     // ---- fused adjoint tail: complex pass along alpha + conj(H) + wavelength reduction against pass + float64 reference
     {
         const long PL = (long)NAP * KBP;
