@@ -117,3 +117,27 @@ def test_rows_growing_towards_the_centre(shape):
     m.close()
     print(f"growing rows {shape}: forward {ef:.2e} adjoint {ea:.2e}")
     assert ef < TOL and ea < TOL, (ef, ea)
+
+
+@pytest.mark.parametrize("shape,L,T", [((251, 251), 300, 4), ((251, 251), 64, 1), ((128, 64), 130, 3), ((127, 250), 40, 2),
+                                       ((255, 40), 200, 4), ((200, 131), 129, 4)])
+def test_fused_adjoint_tail(shape, L, T, monkeypatch):
+    """The adjoint's last transform pass with the conj(OTF) product and the wavelength reduction in its epilogue
+    (dft_h2_adjmix_kernel: reference spectroModel.py:175-181 / mixing.py:177-212) against numpy float64 and against the
+    separate pass + reduction kernel (SURFH_ADJ_FUSED=0): first and last admissible row counts (127, 255), a row count
+    equal to its padding (128: the unused mirror of row 0 lies behind the array), one and several super-tiles per
+    k_beta, workgroup pairs that hold one, two or no super-tile, 1 to 4 templates, wavelength padding inside a tile."""
+    rng = np.random.default_rng(shape[0] * 7 + L)
+    out = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("SURFH_ADJ_FUSED", fused)
+        rs = np.random.default_rng(5)
+        m, sotf, specs = build(shape, L, T, rs)
+        cube = rng.standard_normal((L,) + shape) if not out else cube
+        out[fused] = np.asarray(m.adjoint(cube), dtype=np.float64)
+        if fused == "1":
+            ref = np_adjoint(sotf, specs, cube)
+        m.close()
+    e1, e0, d = rel(out["1"], ref), rel(out["0"], ref), rel(out["1"], out["0"])
+    print(f"fused adjoint tail {shape} L={L} T={T}: fused {e1:.2e} separate {e0:.2e} fused vs separate {d:.2e}")
+    assert e1 < TOL and e0 < TOL and d < TOL, (e1, e0, d)
