@@ -71,6 +71,11 @@ int launch_spmm_rows_f16(hipStream_t s, const EllTable &t, const float *src, uns
 int launch_dequant_f16x2(hipStream_t s, const unsigned short *src16, long plane, const float *bscale, float *dst, int NP, long K, int LinP,
                          int nchunk);
 long ymat_from_y_waves(int PS, int Ldet, int aout);
+// normal operator: sum of the forward GEMM's K slabs straight into the adjoint GEMM's operand -- the two fp16 pieces of
+// ymat [NP][LdetP] (rows >= nrows and columns >= Ldet zero) with one power-of-two scale per row, rowmax[NP] = max |row| as
+// bit patterns.  The same bits as y_from_cpart + ymat_from_y + launch_split_rows2h, without materialising y.
+int launch_ymat16_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit, unsigned short *dst16, long plane, unsigned *rowmax,
+                             int NP, int nrows, int Ldet, int LdetP);
 
 // [L][Na][Nb] (wavelength-major, the reference's cube layout) <-> [NBP][NAP][LP] (wavelength innermost)
 int launch_cube_to_lam_inner(hipStream_t s, const float *src, float *dst, int l0, int L, int na, int nb, int nap, int LP);

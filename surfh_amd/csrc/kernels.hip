@@ -695,6 +695,62 @@ __global__ __launch_bounds__(TPB) void ymat_from_y_kernel(const float *__restric
     if (amax) wave_amax_store(fabsf(v), amax, (blockIdx.y * gridDim.x + blockIdx.x) * (TPB / 64) + (threadIdx.x >> 6));
 }
 
+// Normal operator A^T A d: the forward model's output y is only the hand-over to the adjoint, whose GEMM operand
+// ymat[n][l] = y[ps][l][a] (n = ps * aout + a) is again the slab sum in the slabs' own layout.  One workgroup per operand row:
+// sum of the K slabs (same order as y_from_cpart_kernel), the row's maximum, the two fp16 pieces of the row at its
+// power-of-two scale -- the bits y_from_cpart -> ymat_from_y -> rowmax -> split_rows2h produce, in one pass over the slabs.
+__device__ __forceinline__ float f16x2_row_scale(float amax) {         // f16x2_scale_of of gemm_cc16.hip
+    if (!(amax > 0.f)) return 1.f;
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127;
+    int sc = e - 13;
+    sc = sc < -126 ? -126 : (sc > 127 ? 127 : sc);
+    return __uint_as_float((unsigned)(sc + 127) << 23);
+}
+template <int NV>      // float4 per thread: LdetP <= NV * 1024
+__global__ __launch_bounds__(TPB) void ymat16_from_cpart_kernel(const float *__restrict__ cpart, long slab, int nsplit, unsigned short *__restrict__ dst16,
+                                                                long plane, unsigned *__restrict__ rowmax, int nrows, int Ldet, int LdetP) {
+    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+    const int n = blockIdx.x;
+    float4 v[NV];
+    float m = 0.f;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int l = (j * TPB + threadIdx.x) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (n < nrows && l < Ldet) {
+            const long src = (long)n * LdetP + l;
+            for (int k = 0; k < nsplit; ++k) {
+                const float4 x = *reinterpret_cast<const float4 *>(cpart + k * slab + src);
+                s.x += x.x; s.y += x.y; s.z += x.z; s.w += x.w;
+            }
+            if (l + 1 >= Ldet) s.y = 0.f;        // columns beyond Ldet hold the products of the zero rows of W: not part of y
+            if (l + 2 >= Ldet) s.z = 0.f;
+            if (l + 3 >= Ldet) s.w = 0.f;
+        }
+        v[j] = s;
+        m = fmaxf(m, fmaxf(fmaxf(fabsf(s.x), fabsf(s.y)), fmaxf(fabsf(s.z), fabsf(s.w))));
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float sm[TPB / 64];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    if (threadIdx.x == 0) rowmax[n] = __float_as_uint(m);
+    const float inv = 1.f / f16x2_row_scale(m);
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const int l = (j * TPB + threadIdx.x) * 4;
+        if (l >= LdetP) continue;
+        const float x0 = v[j].x * inv, x1 = v[j].y * inv, x2 = v[j].z * inv, x3 = v[j].w * inv;
+        const _Float16 h0 = (_Float16)x0, h1 = (_Float16)x1, h2 = (_Float16)x2, h3 = (_Float16)x3;
+        f16x4 h = {h0, h1, h2, h3};
+        f16x4 lo = {(_Float16)(x0 - (float)h0), (_Float16)(x1 - (float)h1), (_Float16)(x2 - (float)h2), (_Float16)(x3 - (float)h3)};
+        const long o = (long)n * LdetP + l;
+        *reinterpret_cast<f16x4 *>(dst16 + o) = h;
+        *reinterpret_cast<f16x4 *>(dst16 + plane + o) = lo;
+    }
+}
+
 __global__ __launch_bounds__(TPB) void fill_zero_kernel(float *p, long n) {
     long i = (long)blockIdx.x * TPB + threadIdx.x;
     const long stride = (long)gridDim.x * TPB;
@@ -1140,6 +1196,19 @@ int launch_ymat_from_y(hipStream_t s, const float *y, float *ymat, int PS, int L
     if (pmax)
         hipLaunchKernelGGL(rowmax_contiguous_kernel, dim3((NP + TPB - 1) / TPB), dim3(TPB), 0, s, pmax, (int)grid.x * (TPB / 64), PS * aout,
                            NP, rowmax);
+    return (int)hipGetLastError();
+}
+
+int launch_ymat16_from_cpart(hipStream_t s, const float *cpart, long slab, int nsplit, unsigned short *dst16, long plane, unsigned *rowmax,
+                             int NP, int nrows, int Ldet, int LdetP) {
+    if (LdetP % 4 || slab % 4 || plane % 4 || LdetP > 4 * 4 * TPB || nrows > NP) return (int)hipErrorInvalidValue;
+    const int nv = (LdetP + 4 * TPB - 1) / (4 * TPB);
+#define SURFH_Y16(NV_) hipLaunchKernelGGL(ymat16_from_cpart_kernel<NV_>, dim3(NP), dim3(TPB), 0, s, cpart, slab, nsplit, dst16, plane, rowmax, nrows, Ldet, LdetP)
+    if (nv <= 1) SURFH_Y16(1);
+    else if (nv == 2) SURFH_Y16(2);
+    else if (nv == 3) SURFH_Y16(3);
+    else SURFH_Y16(4);
+#undef SURFH_Y16
     return (int)hipGetLastError();
 }
 

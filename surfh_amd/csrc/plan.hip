@@ -930,7 +930,9 @@ int adjoint_tail(surfh_plan *p, const float *cube) {
     return 0;
 }
 
-int forward_dev(surfh_plan *p, const float *x, float *y) {
+// `hand_over`: the caller is the normal operator -- channels with a spectral-blur GEMM do not write y but leave the adjoint's
+// GEMM operand (fp16 pieces of ymat + row maxima) behind
+int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false) {
     hipStream_t s = p->stream;
     if (p->T > 0) {
         {
@@ -995,7 +997,11 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
                 LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
         }
-        {
+        if (hand_over && c.ymat16) {
+            Prof pr(p, "ymat16_from_cpart", sB);
+            LAUNCH_OK(launch_ymat16_from_cpart(sB, c.Cpart, (long)c.NP * c.LdetP, c.splitK, c.ymat16, (long)c.NP * c.LdetP, c.amax, c.NP,
+                                               c.P * c.S * c.aout, c.Ldet, c.LdetP));
+        } else {
             Prof pr(p, "y_from_cpart", sB);
             LAUNCH_OK(launch_y_from_cpart(sB, c.Cpart, (long)c.NP * c.LdetP, c.splitK, y + c.yoff, c.P * c.S, c.Ldet,
                                           c.aout, c.LdetP));
@@ -1005,7 +1011,8 @@ int forward_dev(surfh_plan *p, const float *x, float *y) {
     return 0;
 }
 
-int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
+// `handed_over`: forward_dev(hand_over) has just left the GEMM operands of the channels with a spectral blur behind
+int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_over = false) {
     hipStream_t s = p->stream;
     // detector-side work (y -> ymat, R^T GEMM) on the second stream, cube-side scatter on the main one: GEMM(c+1)
     // overlaps scatter(c); the scatters stay in channel order on one stream because their windows overlap
@@ -1035,7 +1042,8 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             continue;
         }
         const bool f16 = c.W16 != nullptr;
-        {
+        const bool have16 = handed_over && f16 && c.ymat16;
+        if (!have16) {
             Prof pr(p, "ymat_from_y", sB);
             LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax : nullptr,
                                          f16 ? c.amax : nullptr, c.NP));
@@ -1052,7 +1060,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
             } else {
                 g.ldb = c.LdetP;                     // B as [N'=k][K'=l']
                 g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
-                LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
+                if (!have16) LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
                 g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
                 LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
@@ -1085,8 +1093,12 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref) {
 }
 
 int normal_dev(surfh_plan *p, const float *d, float *q, double mu) {
-    if (forward_dev(p, d, p->cg_y)) return 1;
-    if (adjoint_dev(p, p->cg_y, q, false)) return 1;
+    // y is only the hand-over between the two halves: the channels' slab sums go straight into the adjoint's GEMM operands
+    // (SURFH_NORMAL_FUSED=0: through y, as forward() + adjoint() do)
+    static const bool fused = [] { const char *e = getenv("SURFH_NORMAL_FUSED"); return !(e && e[0] == '0'); }();
+    const bool ho = fused && !p->verify && !p->wblur_fp32;
+    if (forward_dev(p, d, p->cg_y, ho)) return 1;
+    if (adjoint_dev(p, p->cg_y, q, false, ho)) return 1;
     if (mu != 1.0) {
         Prof pr(p, "scale");
         LAUNCH_OK(launch_scale(p->stream, q, p->isize, (float)mu));

@@ -232,6 +232,10 @@ def test_fwadj_and_linearity(c1):
     rng = np.random.default_rng(3)
     x1, x2 = rng.standard_normal(om.ishape), rng.standard_normal(om.ishape)
     assert rel(m.fwadj(x1), m.adjoint(m.forward(x1))) < 1e-6
+    # the normal operator hands the forward GEMM's slab sums straight to the adjoint GEMM as fp16 pieces (ymat16_from_cpart):
+    # the same bits as the way through y
+    assert np.array_equal(m.fwadj(x1), m.adjoint(m.forward(x1)))
+    assert np.array_equal(m.fwadj(x2), m.adjoint(m.forward(x2)))
     assert rel(m.forward(2.0 * x1 - 0.5 * x2), 2.0 * m.forward(x1) - 0.5 * m.forward(x2)) < 1e-5
 
 
