@@ -1,5 +1,6 @@
 // HBM-bound kernels of the surfh hot path for gfx950 (see kernels.h for the contracts).
 #include "kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -439,15 +440,18 @@ __global__ __launch_bounds__(TPB) void spmm_group_scatter_kernel(GroupTable t, c
 #pragma unroll
     for (int g = 0; g < SCATTER_G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     int e = 0;
-    for (; e + 2 <= n; e += 2) {
-        const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
-        const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
+    constexpr int SCATTER_UNROLL = 4;      // taps in flight (2, 4, 8, 16 measured alike: 0.31-0.33 ms per step)
+    for (; e + SCATTER_UNROLL <= n; e += SCATTER_UNROLL) {
+        float4 xv[SCATTER_UNROLL];
 #pragma unroll
-        for (int g = 0; g < SCATTER_G; ++g) {
-            const float v0 = val[e * SCATTER_G + g], v1 = val[(e + 1) * SCATTER_G + g];
-            acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
-            acc[g].x += v1 * x1.x; acc[g].y += v1 * x1.y; acc[g].z += v1 * x1.z; acc[g].w += v1 * x1.w;
-        }
+        for (int u = 0; u < SCATTER_UNROLL; ++u) xv[u] = *reinterpret_cast<const float4 *>(src + col[e + u] + l4);
+#pragma unroll
+        for (int u = 0; u < SCATTER_UNROLL; ++u)
+#pragma unroll
+            for (int g = 0; g < SCATTER_G; ++g) {
+                const float v0 = val[(e + u) * SCATTER_G + g];
+                acc[g].x += v0 * xv[u].x; acc[g].y += v0 * xv[u].y; acc[g].z += v0 * xv[u].z; acc[g].w += v0 * xv[u].w;
+            }
     }
     for (; e < n; ++e) {
         const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
@@ -554,15 +558,20 @@ __global__ __launch_bounds__(TPB) void spmm_group_gather_f16_kernel(GroupTable t
         const int64_t *col = t.col + (long)gi * t.W;
         const float *val = t.val + (long)gi * t.W * SCATTER_G;
         int e = 0;
-        for (; e + 2 <= n; e += 2) {
-            const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
-            const float4 x1 = *reinterpret_cast<const float4 *>(src + col[e + 1] + l4);
+        // eight taps requested before the first is used: with two the kernel waited on memory latency (0.45 -> 0.34 ms per
+        // step on config 3; 4: 0.36, 12 / 16 / 24: 0.36 / 0.38 / 0.36; fewer resident workgroups only cost time)
+        constexpr int GATHER_UNROLL = 8;
+        for (; e + GATHER_UNROLL <= n; e += GATHER_UNROLL) {
+            float4 xv[GATHER_UNROLL];
 #pragma unroll
-            for (int g = 0; g < SCATTER_G; ++g) {
-                const float v0 = val[e * SCATTER_G + g], v1 = val[(e + 1) * SCATTER_G + g];
-                acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
-                acc[g].x += v1 * x1.x; acc[g].y += v1 * x1.y; acc[g].z += v1 * x1.z; acc[g].w += v1 * x1.w;
-            }
+            for (int u = 0; u < GATHER_UNROLL; ++u) xv[u] = *reinterpret_cast<const float4 *>(src + col[e + u] + l4);
+#pragma unroll
+            for (int u = 0; u < GATHER_UNROLL; ++u)
+#pragma unroll
+                for (int g = 0; g < SCATTER_G; ++g) {
+                    const float v0 = val[(e + u) * SCATTER_G + g];
+                    acc[g].x += v0 * xv[u].x; acc[g].y += v0 * xv[u].y; acc[g].z += v0 * xv[u].z; acc[g].w += v0 * xv[u].w;
+                }
         }
         for (; e < n; ++e) {
             const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
