@@ -157,6 +157,11 @@ struct surfh_plan {
     // mhat when T == 0) are then INTERLEAVED [..][LP][2] instead of planar [2][..][LP]
     bool h2 = false;
     unsigned short *h2img = nullptr;             // three images: (Cma, Sma), (Gc, Gs), (Cf, Sf)
+    // cube columns alpha in [a_lo, a_hi) hold every pixel any channel's tables touch: the transform passes that are batched
+    // over alpha skip the rest (forward: the cube outside is never read; adjoint: it is zero).  ycol_adj: the adjoint's
+    // intermediate in its own buffer, whose columns outside the range stay zero from plan creation on.
+    int a_lo = 0, a_hi = 0;
+    float *ycol_adj = nullptr;
     float *adjmix_part = nullptr;                // fused adjoint tail (dft_h2_adjmix_kernel): partial sums per (k_beta, slot); null: off
     int h2kA[3] = {0, 0, 0};
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
@@ -481,6 +486,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
             t.dst.push_back(px.first);
         }
         if (upload_ell(t, &c->adjT)) return 1;
+        for (int64_t o : t.dst) { const int ia = (int)((o / LP) % p->NAP); p->a_lo = std::min(p->a_lo, ia); p->a_hi = std::max(p->a_hi, ia + 1); }
         c->adjT.host_dst = t.dst;
         c->adjT_host = std::move(t);
     }
@@ -518,6 +524,7 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                 t.dst.push_back(pix_off(ia, ib));
             }
         if (upload_ell(t, &c->adjRef)) return 1;
+        for (int64_t o : t.dst) { const int ia = (int)((o / LP) % p->NAP); p->a_lo = std::min(p->a_lo, ia); p->a_hi = std::max(p->a_hi, ia + 1); }
     }
 
     // ---- spectral PSF as GEMM operands: W[l'][b'*LinP + shift + l] = wpsf[l'][l][b'] -------------
@@ -802,19 +809,24 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
 // cube [NBP][NAP][LP] -> spec [KAP][KBP][LP][2]        (tmp ycol viewed as Z[KBP][NAP][LP][2])
 // `madj` != nullptr: the second pass does not store the spectrum but multiplies it by conj(sotf) and reduces it over the
 // wavelengths with the template weights straight into madj [T][2][KAP][KBP] (the adjoint's tail, spectroModel.py:175-181)
-int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = nullptr) {
+// `acols`: the source cube is zero outside the alpha range [a_lo, a_hi) (the adjoint's accumulator): the first pass
+// transforms only those columns, into ycol_adj whose other columns are zero for good
+int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = nullptr, bool acols = false) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
+    const bool sub = acols && p->ycol_adj && p->a_hi > p->a_lo;
+    float *const yc = sub ? p->ycol_adj : p->ycol;
+    const int a0 = sub ? p->a_lo : 0, na = sub ? p->a_hi - p->a_lo : p->Na;
     DftH2Args g;   // r2c along beta
-    g.kind = 1; g.src = src; g.ldb = p->NAP * LP; g.Kn = p->Nb;
-    g.dst = p->ycol; g.ldc = 2 * p->NAP * LP; g.e[0] = 1.f; g.e[3] = -1.f; g.rvalid = hb;
-    g.KP = p->KPb; g.N = (int)(p->Na * LP);
+    g.kind = 1; g.src = src + (long)a0 * LP; g.ldb = p->NAP * LP; g.Kn = p->Nb;
+    g.dst = yc + 2 * (long)a0 * LP; g.ldc = 2 * p->NAP * LP; g.e[0] = 1.f; g.e[3] = -1.f; g.rvalid = hb;
+    g.KP = p->KPb; g.N = (int)(na * LP);
     {
         Prof pr(p, "dft_h2_rows_fwd");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img + 2 * DFT_H2_IMAGE_HALFS, p->h2kA[2]));
     }
     DftH2Args h;   // c2c along alpha, batched over k_beta
-    h.kind = 0; h.src = p->ycol; h.ldb = 2 * LP; h.sB = 2 * p->NAP * LP; h.Kn = p->Na;
+    h.kind = 0; h.src = yc; h.ldb = 2 * LP; h.sB = 2 * p->NAP * LP; h.Kn = p->Na;
     h.dst = dst; h.ldc = 2 * p->KBP * LP; h.sC = 2 * LP; h.Rn = p->Na; h.rvalid = ha;
     h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
     h.e[0] = 1.f; h.e[1] = 1.f; h.e[2] = 1.f; h.e[3] = -1.f;                 // Re Z[r] = C ae + S bo, Re Z[N-r] = C ae - S bo
@@ -834,7 +846,8 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = null
 }
 
 // spec [KAP][KBP][LP][2] -> cube [NBP][NAP][LP]        (tmp ycol viewed as Y[NAP][KBP][LP][2])
-int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix) {
+// `acols`: only the cube columns alpha in [a_lo, a_hi) are wanted (the gathers read nothing else)
+int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
     DftH2Args g;   // c2c along alpha (optionally with the spectral mix formed in the loader)
@@ -848,11 +861,13 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix) {
         Prof pr(p, mix ? "dft_h2_cols_inv_mix" : "dft_h2_cols_inv");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img, p->h2kA[0]));
     }
+    const bool sub = acols && p->a_hi > p->a_lo;
+    const int a0 = sub ? p->a_lo : 0, na = sub ? p->a_hi - p->a_lo : p->Na;
     DftH2Args h;   // c2r along beta, batched over alpha: cube[b] = Gc Yr - Gs Yi, cube[N-b] = Gc Yr + Gs Yi
-    h.kind = 2; h.src = p->ycol; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
-    h.dst = dst; h.ldc = p->NAP * LP; h.sC = LP;
+    h.kind = 2; h.src = p->ycol + (long)a0 * 2 * p->KBP * LP; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
+    h.dst = dst + (long)a0 * LP; h.ldc = p->NAP * LP; h.sC = LP;
     h.e[0] = 1.f; h.e[1] = -1.f; h.e[2] = 1.f; h.e[3] = 1.f; h.Rn = p->Nb; h.rvalid = hb;
-    h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
+    h.KP = p->KPb; h.N = (int)LP; h.batch = na;
     {
         Prof pr(p, "dft_h2_rows_inv");
         LAUNCH_OK(launch_dft_h2(p->stream, h, p->h2img + DFT_H2_IMAGE_HALFS, p->h2kA[1]));
@@ -887,8 +902,8 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
     return 0;
 }
 
-int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = false) {
-    if (p->h2) return irfft2_lam_h2(p, src, dst, mix);
+int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
+    if (p->h2) return irfft2_lam_h2(p, src, dst, mix, acols);
     if (p->rx3) return irfft2_lam_rx3(p, src, dst, mix);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -919,11 +934,14 @@ int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = fals
 // pipelines on device buffers
 // ---------------------------------------------------------------------------------------------
 int rfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? rfft2_lam(p, src, dst) : rfft2_lam_fold(p, src, dst); }
-int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false) { return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_fold(p, src, dst, mix); }
+int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
+    return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_fold(p, src, dst, mix, acols);
+}
 
 // mhat[t] = sum_l tpl[t][l] conj(sotf[l]) rfft2(cube[l])  (T > 0), or the per-plane product (T == 0)
-int adjoint_tail(surfh_plan *p, const float *cube) {
-    if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->mhat);
+// `acols`: the cube is zero outside the alpha range of the channels' tables (the adjoint's accumulator)
+int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
+    if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->mhat, acols);
     if (rfft2_cube(p, cube, p->spec)) return 1;
     Prof pr(p, "specmix_adj");
     LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->h2));
@@ -950,7 +968,8 @@ int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false)
     }
     if (p->T > 0 && p->fuse_mix && !p->dense_dft && !(p->rx3 && p->T > 4)) {
         // spectral mix x OTF fused into the loader of the first inverse pass: `spec` is never written
-        if (irfft2_cube(p, p->sotf, p->cube, true)) return 1;
+        // (the normal operator needs the blurred cube only where a gather reads it)
+        if (irfft2_cube(p, p->sotf, p->cube, true, hand_over)) return 1;
     } else {
         {
             Prof pr(p, "specmix_fwd");
@@ -1076,7 +1095,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
                 LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, acc, c.nlam, 1));
         }
     }
-    if (adjoint_tail(p, acc)) return 1;
+    if (adjoint_tail(p, acc, true)) return 1;
     if (p->T > 0) {
         if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
         Prof pr(p, "unpad_planes");
@@ -1154,6 +1173,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipFree(p->dft3);
     hipFree(p->h2img);
     hipFree(p->adjmix_part);
+    hipFree(p->ycol_adj);
     hipFree(p->dscal);
     hipFree(p->dscratch);
     hipFree(p->cg_hist);
@@ -1425,6 +1445,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     hipMemset(p->maps_pad, 0, nmaps * sizeof(float));
     hipMemset(p->ycol_maps, 0, nycm * sizeof(float));
     // ---- channels -------------------------------------------------------------------------
+    p->a_lo = 1 << 30; p->a_hi = 0;            // alpha range of the pixels the channels' tables touch (build_channel)
     p->ch.resize(cfg->n_channels);
     long yoff = 0;
     for (int i = 0; i < cfg->n_channels; ++i) {
@@ -1453,6 +1474,16 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));
     }
     p->osize = yoff;
+    if (p->a_hi <= p->a_lo) { p->a_lo = 0; p->a_hi = p->Na; }
+    {   // transform passes batched over alpha skip the columns no table touches (SURFH_ALPHA_RANGE=0: whole cube)
+        const char *ear = getenv("SURFH_ALPHA_RANGE");
+        if (ear && ear[0] == '0') { p->a_lo = 0; p->a_hi = p->Na; }
+        if (p->h2 && p->a_hi - p->a_lo < p->Na) {      // the adjoint's intermediate: columns outside the range zero for good
+            const size_t nyc = (size_t)2 * p->NAP * p->KBP * p->LP;
+            if (dev_alloc(&p->ycol_adj, nyc)) return bail(1);
+            if (hipMemset(p->ycol_adj, 0, nyc * sizeof(float)) != hipSuccess) return bail(fail("memset failed"));
+        }
+    }
     {   // The adjoint scatters channel after channel into the cleared cube.  A (pixel, 1024-wavelength chunk) of channel c
         // must be read-modify-written only if an earlier channel's table has that pixel and its window reaches into the
         // chunk; everywhere else the destination is still zero and the kernel stores without reading (the windows of
