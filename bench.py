@@ -122,7 +122,8 @@ def main():
     t0 = time.time()
     fus = DistributedFusion(prob, rank=rank, world=world, device=local)
     m = fus.model
-    log(f"[rank {rank}] plan built in {time.time() - t0:.1f}s; units {fus.units}; osize {m.osize}")
+    log(f"[rank {rank}] plan built in {time.time() - t0:.1f}s; units {fus.units}; osize {m.osize}; "
+        f"cube columns x rows the tables touch [a_lo, a_hi) x [b_lo, b_hi) = {[int(v) for v in m.debug_buffer('range')]}")
     y = fus.make_data(prob["maps"])
     mu, mu_reg = 1.0, 5e3
     fus.start(y, mu, mu_reg, x0=None)

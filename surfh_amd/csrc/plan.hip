@@ -160,7 +160,7 @@ struct surfh_plan {
     // cube columns alpha in [a_lo, a_hi) hold every pixel any channel's tables touch: the transform passes that are batched
     // over alpha skip the rest (forward: the cube outside is never read; adjoint: it is zero).  ycol_adj: the adjoint's
     // intermediate in its own buffer, whose columns outside the range stay zero from plan creation on.
-    int a_lo = 0, a_hi = 0;
+    int a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;  // (b: the same for the cube rows beta)
     float *ycol_adj = nullptr;
     float *adjmix_part = nullptr;                // fused adjoint tail (dft_h2_adjmix_kernel): partial sums per (k_beta, slot); null: off
     int h2kA[3] = {0, 0, 0};
@@ -486,7 +486,11 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
             t.dst.push_back(px.first);
         }
         if (upload_ell(t, &c->adjT)) return 1;
-        for (int64_t o : t.dst) { const int ia = (int)((o / LP) % p->NAP); p->a_lo = std::min(p->a_lo, ia); p->a_hi = std::max(p->a_hi, ia + 1); }
+        for (int64_t o : t.dst) {
+            const int ia = (int)((o / LP) % p->NAP), ib = (int)((o / LP) / p->NAP);
+            p->a_lo = std::min(p->a_lo, ia); p->a_hi = std::max(p->a_hi, ia + 1);
+            p->b_lo = std::min(p->b_lo, ib); p->b_hi = std::max(p->b_hi, ib + 1);
+        }
         c->adjT.host_dst = t.dst;
         c->adjT_host = std::move(t);
     }
@@ -524,7 +528,11 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
                 t.dst.push_back(pix_off(ia, ib));
             }
         if (upload_ell(t, &c->adjRef)) return 1;
-        for (int64_t o : t.dst) { const int ia = (int)((o / LP) % p->NAP); p->a_lo = std::min(p->a_lo, ia); p->a_hi = std::max(p->a_hi, ia + 1); }
+        for (int64_t o : t.dst) {
+            const int ia = (int)((o / LP) % p->NAP), ib = (int)((o / LP) / p->NAP);
+            p->a_lo = std::min(p->a_lo, ia); p->a_hi = std::max(p->a_hi, ia + 1);
+            p->b_lo = std::min(p->b_lo, ib); p->b_hi = std::max(p->b_hi, ib + 1);
+        }
     }
 
     // ---- spectral PSF as GEMM operands: W[l'][b'*LinP + shift + l] = wpsf[l'][l][b'] -------------
@@ -1445,7 +1453,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     hipMemset(p->maps_pad, 0, nmaps * sizeof(float));
     hipMemset(p->ycol_maps, 0, nycm * sizeof(float));
     // ---- channels -------------------------------------------------------------------------
-    p->a_lo = 1 << 30; p->a_hi = 0;            // alpha range of the pixels the channels' tables touch (build_channel)
+    p->a_lo = p->b_lo = 1 << 30; p->a_hi = p->b_hi = 0;      // alpha / beta range of the pixels the channels' tables touch (build_channel)
     p->ch.resize(cfg->n_channels);
     long yoff = 0;
     for (int i = 0; i < cfg->n_channels; ++i) {
@@ -1475,9 +1483,10 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     }
     p->osize = yoff;
     if (p->a_hi <= p->a_lo) { p->a_lo = 0; p->a_hi = p->Na; }
+    if (p->b_hi <= p->b_lo) { p->b_lo = 0; p->b_hi = p->Nb; }
     {   // transform passes batched over alpha skip the columns no table touches (SURFH_ALPHA_RANGE=0: whole cube)
         const char *ear = getenv("SURFH_ALPHA_RANGE");
-        if (ear && ear[0] == '0') { p->a_lo = 0; p->a_hi = p->Na; }
+        if (ear && ear[0] == '0') { p->a_lo = 0; p->a_hi = p->Na; p->b_lo = 0; p->b_hi = p->Nb; }
         if (p->h2 && p->a_hi - p->a_lo < p->Na) {      // the adjoint's intermediate: columns outside the range zero for good
             const size_t nyc = (size_t)2 * p->NAP * p->KBP * p->LP;
             if (dev_alloc(&p->ycol_adj, nyc)) return bail(1);
@@ -2261,6 +2270,8 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
             }
             *ptr = p->ch[c].Xs; dims[0] = p->ch[c].NP; dims[1] = p->ch[c].bsum ? 1 : p->ch[c].nbs; dims[2] = p->ch[c].LinP;
         }
+    } else if (w == "range") {         // cube columns / rows the channels' tables touch: [a_lo, a_hi) x [b_lo, b_hi)
+        dims[0] = p->a_lo; dims[1] = p->a_hi; dims[2] = p->b_lo; dims[3] = p->b_hi;
     } else if (w == "info") {
         dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->Lown; dims[3] = (int64_t)p->segs.size();
     } else {
