@@ -19,14 +19,15 @@
  *     which restates instru.py / slicer.py; the library only consumes them.
  *   - arithmetic type: fp32 on device.  The dense stages evaluate every fp32 product as a few 16-bit
  *     matrix-core products of split operands, accumulated in fp32: the spectral blur as three products of a
- *     two-piece round-to-nearest fp16 split (22 mantissa bits), the DFT passes as six products of an exact
- *     three-piece bf16 split (fp32-input MFMA kernels behind SURFH_* environment switches); inner products
- *     of the solvers accumulate in fp64.
- *   - environment switches read at plan creation (A/B paths, all parity-tested): SURFH_DFT_RX3=0,
- *     SURFH_FOLD2=1, SURFH_DFT_DENSE=1, SURFH_NO_FUSED_MIX=1, SURFH_DFT_PACKED=0, SURFH_WBLUR_FP32=1,
- *     SURFH_WBLUR_F16=0, SURFH_WBLUR_CC=0|1, SURFH_WBLUR_PC=0, SURFH_WBLUR_PRESPLIT=0, SURFH_GATHER_SORTED=0, SURFH_GATHER_GROUPED=0,
- *     SURFH_SCATTER_GROUPED=0, SURFH_SCATTER_RMW_ALL=1,
- *     SURFH_OVERLAP=1.
+ *     two-piece round-to-nearest fp16 split (22 mantissa bits) with per-row / per-segment operand scales, the DFT passes
+ *     the same way under a per-column running block exponent (image sizes beyond their limits: six products of an exact
+ *     three-piece bf16 split); fp32-input MFMA kernels behind SURFH_* environment switches; inner products of the
+ *     solvers accumulate in fp64.  surfh_config.verify selects float64-accumulating kernels throughout.
+ *   - environment switches read at plan creation (A/B paths, all parity-tested): SURFH_DFT_H2=0, SURFH_DFT_RX3=0,
+ *     SURFH_DFT_DENSE=1, SURFH_NO_FUSED_MIX=1, SURFH_DFT_PACKED=0, SURFH_WBLUR_FP32=1, SURFH_ADJ_FUSED=0 (separate
+ *     adjoint reduction kernel), SURFH_ALPHA_RANGE=0 (transform the whole cube), SURFH_GATHER_SORTED=0,
+ *     SURFH_GATHER_GROUPED=0, SURFH_SCATTER_GROUPED=0, SURFH_SCATTER_RMW_ALL=1, SURFH_ADJ_CLEAR=1, SURFH_OVERLAP=1;
+ *     read once per process: SURFH_NORMAL_FUSED=0 (the normal operator goes through y).
  */
 #ifndef SURFH_AMD_H
 #define SURFH_AMD_H

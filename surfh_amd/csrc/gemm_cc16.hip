@@ -31,7 +31,7 @@ constexpr int PIECE = ROWS * BK;              // one fp16 piece of one stage (el
 constexpr int STAGE = 2 * PIECE;              // 64 KB
 constexpr size_t LDS_BYTES = (size_t)2 * STAGE * sizeof(unsigned short);
 
-// power of two that brings `amax` to [2^13, 2^14); 1 for an all-zero row (the same function as in gemm_pc16.hip)
+// power of two that brings `amax` to [2^13, 2^14); 1 for an all-zero row (the gather uses the same function: f16x2_block_scale, kernels.hip)
 __device__ __forceinline__ float f16x2_scale_of(float amax) {
     if (!(amax > 0.f)) return 1.f;
     const int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127;

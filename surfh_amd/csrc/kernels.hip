@@ -482,7 +482,7 @@ __global__ __launch_bounds__(TPB) void spmm_group_scatter_kernel(GroupTable t, c
 // per workgroup, i.e. per (operand row, segment of <= 1024 wavelengths of one beta column): the workgroup's maximum is known
 // before anything is stored, so no second pass over the operand is needed, and the scale is finer than one per row.
 // bscale[seg][NP] receives the power of two; seg = (column offset / LinP) * nchunk + chunk.
-__device__ __forceinline__ float f16x2_block_scale(float amax) {       // as f16x2_scale_of in gemm_pc16.hip / gemm_cc16.hip
+__device__ __forceinline__ float f16x2_block_scale(float amax) {       // as f16x2_scale_of in gemm_cc16.hip
     if (!(amax > 0.f)) return 1.f;
     const int e = (int)((__float_as_uint(amax) >> 23) & 0xFF) - 127;
     int sc = e - 13;

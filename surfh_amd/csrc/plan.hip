@@ -97,7 +97,7 @@ struct Channel {
     int K = 0, NP = 0, LdetP = 0, splitK = 1;
     long yoff = 0, ysize = 0;
     float *W = nullptr, *Wt = nullptr, *Xs = nullptr, *Cpart = nullptr, *ymat = nullptr;
-    unsigned short *W16 = nullptr, *Wt16 = nullptr; // ... or into their two fp16 pieces [2][rows][cols] of W / sW (gemm_pc16.hip)
+    unsigned short *W16 = nullptr, *Wt16 = nullptr; // ... or into their two fp16 pieces [2][rows][cols] of W / sW (gemm_cc16.hip)
     unsigned short *Xs16 = nullptr, *ymat16 = nullptr;   // the data operands as fp16 pieces (all-consumer kernel, gemm_cc16.hip)
     float *bscale = nullptr;                        // Xs16's scales, one per (row, K segment): [nbs * ceil(LinP/1024)][NP]
     float sW = 1.f;

@@ -422,17 +422,13 @@ def test_disjoint_wavelength_windows(lmm):
     m.close()
 
 
-@pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_RX3": "0", "SURFH_FOLD2": "1"},
-                                 {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
-                                 {"SURFH_WBLUR_PC": "0"}, {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_H2": "0", "SURFH_DFT_PACKED": "0"},
-                                 {"SURFH_DFT_H2": "0"},
-                                 {"SURFH_WBLUR_F16": "0"}, {"SURFH_WBLUR_F16": "0", "SURFH_WBLUR_PRESPLIT": "0"},
-                                 {"SURFH_GATHER_SORTED": "0"}, {"SURFH_SCATTER_RMW_ALL": "1"}, {"SURFH_WBLUR_CC": "0"},
-                                 {"SURFH_WBLUR_CC": "1"}, {"SURFH_SCATTER_GROUPED": "0"}, {"SURFH_GATHER_GROUPED": "0"}],
-                         ids=["fold_fp32", "fold_fp32_two_launch", "dense_dft", "unfused_mix", "wblur_fp32", "wblur_4wave",
-                              "two_streams", "dft_bf16_two_pass_complex", "dft_bf16_three_piece", "wblur_bf16_three_piece", "wblur_bf16_split_in_kernel",
-                              "gather_rows_unsorted", "scatter_rmw_everywhere", "wblur_producer_consumer", "wblur_cc_adjoint_only",
-                              "scatter_row_by_row", "gather_row_by_row"])
+@pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
+                                 {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_H2": "0", "SURFH_DFT_PACKED": "0"}, {"SURFH_DFT_H2": "0"},
+                                 {"SURFH_GATHER_SORTED": "0"}, {"SURFH_SCATTER_RMW_ALL": "1"}, {"SURFH_SCATTER_GROUPED": "0"},
+                                 {"SURFH_GATHER_GROUPED": "0"}, {"SURFH_ALPHA_RANGE": "0"}, {"SURFH_ADJ_FUSED": "0"}, {"SURFH_ADJ_CLEAR": "1"}],
+                         ids=["fold_fp32", "dense_dft", "unfused_mix", "wblur_fp32", "two_streams", "dft_bf16_two_pass_complex",
+                              "dft_bf16_three_piece", "gather_rows_unsorted", "scatter_rmw_everywhere", "scatter_row_by_row",
+                              "gather_row_by_row", "transform_whole_cube", "adjoint_tail_separate", "adjoint_clears_accumulator"])
 def test_alternative_kernel_paths(env):
     """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green."""
     cfg = problems.config1()
