@@ -14,10 +14,10 @@
 // step of 32, delivered by LDS-DMA (global_load_lds, no registers, no VALU) into an XOR-swizzled [piece][row][32 k] image,
 // two 64 KB stages.  (A 128 x 256 producer / consumer tile needs 48 KB per K step for half the flops: 60 B/clk per CU, the
 // width of the L1 fill path.)
-// Results are the same bits as the first (compiler-scheduled) version of this kernel: same products, same order.
 #include "gemm_f32.h"
 #include "lds_attr.h"
 #include <cmath>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -57,15 +57,10 @@ __global__ __launch_bounds__(256) void split_rows2h_kernel(const float *__restri
     *reinterpret_cast<f16x4 *>(dst + plane + o) = l;
 }
 
-// The kernel's K loop is hand-scheduled.  hipcc puts s_waitcnt lgkmcnt(0) behind every group of LDS reads and vmcnt(0) in
-// front of LDS accesses while a DMA is in flight; scheduled that way (the first version of this file) the LDS latency was
-// exposed five times per K step and the DMA issue of all eight waves stalled in front of their MFMAs: delivery and matrix-core
-// time ADDED (0.123 + 0.142 ms of a 0.267 ms launch at the config-3 forward shape).  Here the fragment reads, the DMA pieces,
-// the MFMAs and their waits are volatile inline assembly in a fixed interleaved order (LDS reads return in order; vmcnt is
-// one in-order counter): on constant operands the loop runs at the matrix cores' rate (0.157 ms, 1.5 PFLOP/s issued); on
-// random operands the chip lowers its clock under the bit toggling and the launch takes 0.24 ms (tools/exp/cc_main.hip).
-// Register budget: 128 accumulators + 64 fragment registers -- the DMA sources are one 32-bit lane offset per 128-row group
-// on scalar bases and the block scales of A sit in LDS (K segments of this slab x 256 rows).
+// The kernel's K loop is hand-scheduled (described in front of the kernel): hipcc puts s_waitcnt lgkmcnt(0) behind every group
+// of LDS reads and vmcnt(0) in front of LDS accesses while a DMA is in flight.  Register budget: 128 accumulators + 64
+// fragment registers -- the DMA sources are one 32-bit lane offset per 128-row group on scalar bases and the block scales of
+// A sit in LDS (K segments of this slab x 256 rows).
 #ifndef CC_EXP
 #define CC_EXP 0          // experiment mask (tools/exp): 1 no DMA inside the loop, 2 no fragment reads, 4 no MFMAs
 #endif
@@ -99,117 +94,72 @@ __device__ __forceinline__ void cc2_dma(const char *base, unsigned off, unsigned
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(off), "s"(base), "s"(l) : "memory");
 }
 
-// The instruction stream of one K step is four units of 12 MFMAs: unit U = (half step hs = U >> 1, column-block pair
-// jp = U & 1) multiplies the A fragments of its half step (row blocks i = 0, 1) with the B fragments of column blocks
-// j = 2 jp, 2 jp + 1 -- products l*h, h*l, h*h per block, the order of the first kernel.  Behind MFMA n of a unit, so that
-// they issue in the shadow of the matrix cores and of the SIMD's other wave: n < 4 the B fragment reads of the NEXT unit,
-// 4 <= n < 8 (RDA) the A fragment reads of the next half step, and (DMA) eight DMA pieces of a later stage in slots
-// 1, 2, 4, 5, 7, 8, 10, 11.  Everything is volatile assembly: the compiler keeps the order and adds no waits of its own.
-template <int U, int N, bool RDB, bool RDA, bool DMA>
-__device__ __forceinline__ void cc2_slot(f32x16 (&acc)[2][4], const f16x8 (&Ac)[2][2], const f16x8 (&Bc)[2][2], f16x8 (&An)[2][2],
-                                         f16x8 (&Bn)[2][2], unsigned ran, unsigned rbn, const char *ka, const char *kb, long pA2, long pB2,
-                                         const unsigned (&offA)[2], const unsigned (&offB)[2], unsigned ls) {
-    constexpr int jp = U & 1, jj = N / 6, j = 2 * jp + jj, i = (N / 3) & 1, p = N % 3;
+// the accumulators are written by assembly MFMAs the compiler knows nothing about: before ordinary code reads them, let the
+// last one drain
+#define CC_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory")
+
+// ---------------------------------------------------------------------------------------------------------------
+// The K loop on v_mfma_f32_16x16x32_f16, as a fixed interleaved stream of volatile inline assembly (the compiler keeps
+// the order and adds no waits of its own; LDS reads return in order, vmcnt is one in-order counter):
+//   * a K step is one MFMA deep (k = 32): a lane holds 8 consecutive k of one row (row = lane & 15, k chunk = lane >> 4),
+//     and the LDS image is swizzled for that read pattern: chunk c of row r at position c ^ (-(r >> 2) & 3) -- conflict-free
+//     ds_read_b128, no padding; the DMA writes the image lane-linearly, so the swizzle is a permutation of the 16-byte
+//     chunks each lane fetches from its row's 64-byte segment;
+//   * wave tile 64 x 128 = 4 x 8 blocks of 16 x 16, accumulator block = 4 registers (rows 4 (lane >> 4) + r, column lane & 15);
+//   * stream of a K step: four units of 24 MFMAs (unit u = column blocks 2u, 2u + 1; inside a unit row block by row block,
+//     products l*h, h*l, h*h per block).  Behind MFMAs 0..3 of a unit the B fragments of the next unit; in unit 3 the A
+//     fragments of the next K step, each row block's pair right behind the last MFMA that uses the old ones (the registers are
+//     free then), and the eight DMA pieces of K step kt + 2 into the stage just left;
+//   * one barrier per K step, in front of unit 3: every wave then holds the last fragments of stage kt & 1 in registers and
+//     K step kt + 1 has landed (it is each wave's newest DMA).  One instruction stream for every kt: in the last two steps the
+//     DMA repeats the last K step into a stage nobody reads any more and the reads fetch fragments nobody uses.
+// 128 accumulator + 64 fragment registers.  The round-1 loop (32x32x16 MFMAs, compiler-scheduled) spent 0.123 ms on the DMA
+// alone and 0.142 ms on the MFMAs alone and took their SUM; hand-scheduled it reached the matrix cores' rate on constant
+// operands (0.157 ms, 1.5 PFLOP/s issued) and 0.24 ms on random ones: the chip lowers its clock under the bit toggling of real
+// data.  The 16x16x32 shape draws less per flop: 0.225 ms on random operands (0.170 on constant ones) -- tools/exp/cc_main.hip.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+template <int U, int N, bool DMA>
+__device__ __forceinline__ void cc16_slot(f32x4v (&acc)[4][8], f16x8 (&A)[4][2], const f16x8 (&Bc)[2][2], f16x8 (&Bn)[2][2], unsigned ran,
+                                          unsigned rbn, const char *ka, const char *kb, long pA2, long pB2, const unsigned (&offA)[2],
+                                          const unsigned (&offB)[2], unsigned ls) {
+    constexpr int i = N / 6, jj = (N / 3) & 1, j = 2 * U + jj, p = N % 3;
     if constexpr (!(CC_EXP & 4))
-        asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(Ac[i][p == 0 ? 1 : 0]), "v"(Bc[jj][p == 1 ? 1 : 0]));
-    constexpr int R = N;                           // read slot
-    if constexpr (RDB && R < 4 && !(CC_EXP & 2)) {
-        constexpr int jn = 2 * ((U + 1) & 1) + (R >> 1), q = R & 1;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Bn[R >> 1][q]) : "v"(rbn), "n"(q * PIECE * 2 + jn * 32 * BK * 2));
+        asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(A[i][p == 0 ? 1 : 0]), "v"(Bc[jj][p == 1 ? 1 : 0]));
+    if constexpr (N < 4 && !(CC_EXP & 2)) {        // B fragments of the next unit (unit 3: of the next K step's unit 0, other stage)
+        constexpr int jn = 2 * ((U + 1) & 3) + (N >> 1), q = N & 1;
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Bn[N >> 1][q]) : "v"(rbn), "n"(q * PIECE * 2 + jn * 16 * BK * 2));
     }
-    if constexpr (RDA && R >= 4 && R < 8 && !(CC_EXP & 2)) {
-        constexpr int in = (R - 4) >> 1, q = R & 1;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(An[in][q]) : "v"(ran), "n"(q * PIECE * 2 + in * 32 * BK * 2));
+    if constexpr (U == 3 && N % 6 == 5 && !(CC_EXP & 2)) {      // row block i is done with its A fragments: the next K step's follow
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[i][0]) : "v"(ran), "n"(i * 16 * BK * 2));
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[i][1]) : "v"(ran), "n"(PIECE * 2 + i * 16 * BK * 2));
     }
-    constexpr int d = (N % 3 != 0) ? N - 1 - N / 3 : -1;       // pieces 0..7 behind MFMAs 1, 2, 4, 5, 7, 8, 10, 11
+    constexpr int d = (U == 3 && N % 3 != 2 && N < 12) ? N - N / 3 : -1;       // pieces 0..7 behind MFMAs 0, 1, 3, 4, 6, 7, 9, 10
     if constexpr (DMA && d >= 0 && !(CC_EXP & 1)) {
         constexpr int q = d >> 2, i2 = (d >> 1) & 1;
         if constexpr (d & 1) cc2_dma(kb + q * pB2, offB[i2], ls + (unsigned)((q * PIECE + (BM + i2 * 128) * BK) * 2));
         else cc2_dma(ka + q * pA2, offA[i2], ls + (unsigned)((q * PIECE + i2 * 128 * BK) * 2));
     }
 }
-template <int U, bool RDB, bool RDA, bool DMA, int N = 0>
-__device__ __forceinline__ void cc2_unit(f32x16 (&acc)[2][4], const f16x8 (&Ac)[2][2], const f16x8 (&Bc)[2][2], f16x8 (&An)[2][2],
-                                         f16x8 (&Bn)[2][2], unsigned ran, unsigned rbn, const char *ka, const char *kb, long pA2, long pB2,
-                                         const unsigned (&offA)[2], const unsigned (&offB)[2], unsigned ls) {
-    if constexpr (N < 12) {
-        cc2_slot<U, N, RDB, RDA, DMA>(acc, Ac, Bc, An, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
-        cc2_unit<U, RDB, RDA, DMA, N + 1>(acc, Ac, Bc, An, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
+template <int U, bool DMA, int N = 0>
+__device__ __forceinline__ void cc16_unit(f32x4v (&acc)[4][8], f16x8 (&A)[4][2], const f16x8 (&Bc)[2][2], f16x8 (&Bn)[2][2], unsigned ran,
+                                          unsigned rbn, const char *ka, const char *kb, long pA2, long pB2, const unsigned (&offA)[2],
+                                          const unsigned (&offB)[2], unsigned ls) {
+    if constexpr (N < 24) {
+        // unit 0: row block 3's fragments of this K step were requested last in the previous unit 3 (two reads), before this
+        // unit's four B reads: wait for them here
+        if constexpr (U == 0 && N == 18 && !(CC_EXP & 2)) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[3][0]), "+v"(A[3][1]));
+        cc16_slot<U, N, DMA>(acc, A, Bc, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
+        cc16_unit<U, DMA, N + 1>(acc, A, Bc, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
     }
 }
-
-// wait for every LDS read of this wave; the registers are operands so that no use of them can be moved in front of it
-#define CC_WAIT(A_, B_)                                                                                                 \
-    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
-                 : "+v"(A_[0][0]), "+v"(A_[1][0]), "+v"(A_[0][1]), "+v"(A_[1][1]), "+v"(B_[0][0]), "+v"(B_[1][0]), "+v"(B_[0][1]), "+v"(B_[1][1]))
-// the accumulators are written by assembly MFMAs the compiler knows nothing about: before ordinary code reads them, let the
-// last one drain (a 32x32x16 MFMA takes 8 passes of 4 cycles)
-#define CC_MFMA_DRAIN() asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory")
-
-struct Cc2Loop {           // wave-uniform state of the main loop
-    const char *baseA, *baseB;
-    long pA2, pB2;
-    unsigned ldsw;
-    int nk, kbeg;
-    const float *sctab;    // nullptr: one scale per row (amax), no rescaling inside the loop
-    int seg0, seg, seg_end, segLinP, segChunks;
-};
-
-// main loop of a wave; on entry the fragments of unit 0 of stage 0 are in Ae / Bx
-__device__ __forceinline__ void cc2_mainloop(f32x16 (&acc)[2][4], f16x8 (&Ae)[2][2], f16x8 (&Ao)[2][2], f16x8 (&Bx)[2][2], f16x8 (&By)[2][2],
-                                             unsigned ra0, unsigned ra1, unsigned rb0, unsigned rb1, const unsigned (&offA)[2],
-                                             const unsigned (&offB)[2], int srow, Cc2Loop &L) {
-    for (int kt = 0; kt < L.nk; ++kt) {
-        if (L.sctab && L.kbeg + kt * BK >= L.seg_end) {     // workgroup-uniform, once per <= 1024 k
-            const int k = L.kbeg + kt * BK;
-            const int nseg = cc2_seg_of(k, L.segLinP, L.segChunks);
-            L.seg_end = cc2_seg_end(k, L.segLinP);
-            CC_MFMA_DRAIN();
-            const float *to = L.sctab + (L.seg - L.seg0) * BM + srow, *tn_ = L.sctab + (nseg - L.seg0) * BM + srow;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) {
-                    const float4 so = *reinterpret_cast<const float4 *>(to + i * 32 + 8 * r4);
-                    const float4 sn4 = *reinterpret_cast<const float4 *>(tn_ + i * 32 + 8 * r4);
-                    const float ra[4] = {cc2_pow2_ratio(so.x, sn4.x), cc2_pow2_ratio(so.y, sn4.y), cc2_pow2_ratio(so.z, sn4.z),
-                                         cc2_pow2_ratio(so.w, sn4.w)};
-#pragma unroll
-                    for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) acc[i][j][4 * r4 + rr] *= ra[rr];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            L.seg = nseg;
-        }
-        // DMA of K step kt + 2 -> stage kt & 1, issued in unit 3.  One instruction stream for every kt: in the last two steps
-        // the DMA repeats the last K step into a stage nobody reads any more and the reads fetch fragments nobody uses.
-        const int k2 = kt + 2 < L.nk ? kt + 2 : L.nk - 1;
-        const char *ka2 = L.baseA + (long)k2 * (BK * 2), *kb2 = L.baseB + (long)k2 * (BK * 2);
-        const unsigned ls2 = L.ldsw + (unsigned)(kt & 1) * (STAGE * 2);
-        // unit 0 (k 0..15, columns 0..63): reads B of unit 1
-        cc2_unit<0, true, false, false>(acc, Ae, Bx, Ao, By, ra1, rb0, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
-        CC_WAIT(Ae, By);
-        // unit 1 (k 0..15, columns 64..127): reads B of unit 2 and A of the second half step
-        cc2_unit<1, true, true, false>(acc, Ae, By, Ao, Bx, ra1, rb1, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
-        CC_WAIT(Ao, Bx);
-        // unit 2 (k 16..31, columns 0..63): reads B of unit 3, the last fragments of this stage
-        cc2_unit<2, true, false, false>(acc, Ao, Bx, Ae, By, ra0, rb1, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
-        CC_WAIT(Ao, By);
-        // K step kt + 1 landed (this wave's DMAs are all older); every wave holds the last fragments of stage kt & 1 in registers
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        ra0 ^= STAGE * 2; ra1 ^= STAGE * 2; rb0 ^= STAGE * 2; rb1 ^= STAGE * 2;
-        // unit 3 (k 16..31, columns 64..127): reads A and B of the next K step's unit 0 from the other stage
-        cc2_unit<3, true, true, true>(acc, Ao, By, Ae, Bx, ra0, rb0, ka2, kb2, L.pA2, L.pB2, offA, offB, ls2);
-        CC_WAIT(Ae, Bx);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the surplus DMAs must land before the LDS is given back
-    CC_MFMA_DRAIN();
-}
+// wait until at most n_ LDS reads of this wave are outstanding (the B fragments of the next unit are operands)
+#define CC16_WAITB(n_, B_)                                                                                              \
+    asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(B_[0][0]), "+v"(B_[1][0]), "+v"(B_[0][1]), "+v"(B_[1][1]))
 
 __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    float *sctab = reinterpret_cast<float *>(lds + 2 * STAGE);       // [segment - seg0][row of the tile]
+    float *sctab = reinterpret_cast<float *>(lds + 2 * STAGE);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN, tiles = tilesM * tilesN;
     const long total = (long)tiles * g.splitK * g.batch, per = (total + 7) / 8;
@@ -221,16 +171,14 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     const int m0 = tm * BM, n0 = tn * BN;
     const int Kper = g.K / g.splitK, kbeg = sk * Kper, nk = Kper / BK;
 
-    // DMA: one wave instruction moves 16 rows x 64 B of one piece (row = lane >> 2; LDS chunk lane & 3 holds the global
-    // chunk (lane & 3) ^ (lane >> 4 & 3) of the row).  Wave w moves the 16-row groups w, w + 8 (A rows), w + 16, w + 24
-    // (B rows) of both pieces: four lane offsets (bytes) on scalar bases.
+    // DMA: LDS slot lane & 3 of row lane >> 2 (of a 16-row group) holds the global chunk (lane & 3) ^ (-(lane >> 4) & 3)
     unsigned offA[2], offB[2];
     {
-        const int chunk = (lane & 3) ^ ((lane >> 4) & 3);
+        const int chunk = (lane & 3) ^ ((-(lane >> 4)) & 3);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             int m = m0 + (wave + 8 * i) * 16 + (lane >> 2);
-            m = m < g.M ? m : g.M - 1;                 // ragged last tile: clamp, the rows are not stored
+            m = m < g.M ? m : g.M - 1;
             offA[i] = (unsigned)(((long)m * g.lda + 8 * chunk) * 2);
             int n = n0 + (wave + 8 * i) * 16 + (lane >> 2);
             n = n < g.N ? n : g.N - 1;
@@ -240,7 +188,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     const char *baseA = cc2_uniform(reinterpret_cast<const char *>(g.A3 + (long)b * g.sA + kbeg));
     const char *baseB = cc2_uniform(reinterpret_cast<const char *>(g.B16 + (long)b * g.sB + kbeg));
     const long pA2 = g.pA3 * 2, pB2 = g.pB16 * 2;
-    const unsigned ldsw = (unsigned)(size_t)lds + (unsigned)(wave * 16 * BK * 2);     // byte address of the wave's first group
+    const unsigned ldsw = (unsigned)(size_t)lds + (unsigned)(wave * 16 * BK * 2);
 #define CC_DMA(kt_, st_)                                                                                               \
     {                                                                                                                  \
         const char *ka = baseA + (long)(kt_) * (BK * 2), *kb = baseB + (long)(kt_) * (BK * 2);                         \
@@ -252,26 +200,20 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
             }                                                                                                          \
         }                                                                                                              \
     }
-    const int l31 = lane & 31, h = lane >> 5;
+    const int l15 = lane & 15, kc = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves, wave tile 64 x 128
-    f32x16 acc[2][4];
+    f32x4v acc[4][8];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    const int sw = (l31 >> 2) & 3;
-    // fragment byte addresses of the two half steps in stage 0: chunk (2 * s2 + h) ^ sw of the lane's row; the stage is
-    // toggled by XOR with its size
-    unsigned ra0 = (unsigned)(size_t)lds + (unsigned)(((wm * 64 + l31) * BK + ((h ^ sw) * 8)) * 2);
-    unsigned ra1 = (unsigned)(size_t)lds + (unsigned)(((wm * 64 + l31) * BK + (((2 + h) ^ sw) * 8)) * 2);
-    const unsigned fbd = (unsigned)((BM + wn * 128 - wm * 64) * BK * 2);              // B fragment row - A fragment row
-    unsigned rb0 = ra0 + fbd, rb1 = ra1 + fbd;
+        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // fragment byte addresses in stage 0 (the stage is toggled by XOR with its size)
+    unsigned ra = (unsigned)(size_t)lds + (unsigned)(((wm * 64 + l15) * BK + ((kc ^ ((-(l15 >> 2)) & 3)) * 8)) * 2);
+    const unsigned fbd = (unsigned)((BM + wn * 128 - wm * 64) * BK * 2);
+    unsigned rb = ra + fbd;
     const bool active = m0 + wm * 64 < g.M;
 
-    // block-scaled A: the scales of the segments this slab crosses, for the tile's rows, into LDS
-    const float *bs = g.bscale;                    // batch 1 only (checked by the launcher)
+    const float *bs = g.bscale;
     int seg0 = 0, seg = 0, seg_end = 1 << 30;
     if (bs) {
         seg0 = seg = cc2_seg_of(kbeg, g.segLinP, g.segChunks);
@@ -283,26 +225,19 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
             sctab[e] = bs[(long)(seg0 + (e >> 8)) * g.M + row];
         }
     }
-    const int srow = wm * 64 + 4 * h;              // first of the lane's accumulator rows inside the tile
+    const int srow = wm * 64 + 4 * kc;             // first of the lane's accumulator rows inside the tile (row block 0)
 
-    // fragment registers: A of the even / odd half step ([row block][piece]), B of the even / odd unit ([column block][piece])
-    f16x8 Ae[2][2], Ao[2][2], Bx[2][2], By[2][2];
+    f16x8 A[4][2], Bx[2][2], By[2][2];             // A [row block][piece] of the current K step; B [column block][piece] of the even / odd unit
 #define CC_RD(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
     CC_DMA(0, 0);
     if (nk > 1) {
         CC_DMA(1, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // stage 0 landed (one in-order counter)
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __syncthreads();                               // also publishes sctab
-    if (active && !(CC_EXP & 2)) {                 // unit 0 of stage 0
-        CC_RD(Ae[0][0], ra0, 0); CC_RD(Ae[1][0], ra0, 32 * BK * 2); CC_RD(Ae[0][1], ra0, PIECE * 2); CC_RD(Ae[1][1], ra0, PIECE * 2 + 32 * BK * 2);
-        CC_RD(Bx[0][0], rb0, 0); CC_RD(Bx[1][0], rb0, 32 * BK * 2); CC_RD(Bx[0][1], rb0, PIECE * 2); CC_RD(Bx[1][1], rb0, PIECE * 2 + 32 * BK * 2);
-        CC_WAIT(Ae, Bx);
-    }
+    __syncthreads();
     if (!active) {
-        // ragged last row tile: this wave's 64 rows lie beyond M; it only moves data (same barriers, same DMA pieces)
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             const int kd = kt + 2 < nk ? kt + 2 : nk - 1;
@@ -311,38 +246,78 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         return;
     }
-    Cc2Loop L{baseA, baseB, pA2, pB2, ldsw, nk, kbeg, bs ? sctab : nullptr, seg0, seg, seg_end, g.segLinP, g.segChunks};
-    cc2_mainloop(acc, Ae, Ao, Bx, By, ra0, ra1, rb0, rb1, offA, offB, srow, L);
-    seg = L.seg;
+    if (!(CC_EXP & 2)) {                           // fragments of stage 0: A, B of unit 0
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { CC_RD(A[i][0], ra, 0 + 0); CC_RD(A[i][1], ra, PIECE * 2); ra += 16 * BK * 2; }
+        ra -= 4 * 16 * BK * 2;
+        CC_RD(Bx[0][0], rb, 0); CC_RD(Bx[1][0], rb, 16 * BK * 2); CC_RD(Bx[0][1], rb, PIECE * 2); CC_RD(Bx[1][1], rb, PIECE * 2 + 16 * BK * 2);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[3][0]),
+                     "+v"(A[3][1]), "+v"(Bx[0][0]), "+v"(Bx[1][0]), "+v"(Bx[0][1]), "+v"(Bx[1][1]));
+    }
+    for (int kt = 0; kt < nk; ++kt) {
+        if (bs && kbeg + kt * BK >= seg_end) {     // workgroup-uniform, once per <= 1024 k
+            const int k = kbeg + kt * BK;
+            const int nseg = cc2_seg_of(k, g.segLinP, g.segChunks);
+            seg_end = cc2_seg_end(k, g.segLinP);
+            CC_MFMA_DRAIN();
+            const float *to = sctab + (seg - seg0) * BM + srow, *tn_ = sctab + (nseg - seg0) * BM + srow;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float4 so = *reinterpret_cast<const float4 *>(to + i * 16);
+                const float4 sn4 = *reinterpret_cast<const float4 *>(tn_ + i * 16);
+                const f32x4v rt = {cc2_pow2_ratio(so.x, sn4.x), cc2_pow2_ratio(so.y, sn4.y), cc2_pow2_ratio(so.z, sn4.z), cc2_pow2_ratio(so.w, sn4.w)};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[i][j] *= rt;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            seg = nseg;
+        }
+        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;
+        const char *ka2 = baseA + (long)k2 * (BK * 2), *kb2 = baseB + (long)k2 * (BK * 2);
+        const unsigned ls2 = ldsw + (unsigned)(kt & 1) * (STAGE * 2);
+        cc16_unit<0, false>(acc, A, Bx, By, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
+        CC16_WAITB(0, By);
+        cc16_unit<1, false>(acc, A, By, Bx, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
+        CC16_WAITB(0, Bx);
+        cc16_unit<2, false>(acc, A, Bx, By, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
+        CC16_WAITB(0, By);
+        // K step kt + 1 landed; every wave holds the last fragments of stage kt & 1 in registers
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        ra ^= STAGE * 2; rb ^= STAGE * 2;
+        // unit 3: reads from the other stage (B of the next unit 0, A of the next K step), DMA of K step kt + 2
+        cc16_unit<3, true>(acc, A, By, Bx, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
+        CC16_WAITB(2, Bx);                         // all but row block 3's two A fragments (awaited inside the next unit 0)
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    CC_MFMA_DRAIN();
 #undef CC_DMA
 #undef CC_RD
-    if (active) {
+    {
         char *Cb = reinterpret_cast<char *>(g.C + (long)b * g.sC + (long)sk * g.sCsplit + (long)m0 * g.ldc + n0);
         const unsigned ldc4 = (unsigned)(g.ldc * 4);
-        unsigned o_ = (unsigned)srow * ldc4 + (unsigned)(wn * 128 + l31) * 4u;
-        // undo both operand scales (powers of two: exact)
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            float rsc[16];                 // the 16 row scales of this half requested together
+        for (int i = 0; i < 4; ++i) {
+            float rsc[4];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lr = srow + i * 32 + (r & 3) + 8 * (r >> 2);
+            for (int r = 0; r < 4; ++r) {
+                const int lr = srow + i * 16 + r;
                 int row = m0 + lr;
                 row = row < g.M ? row : g.M - 1;
                 rsc[r] = bs ? sctab[(seg - seg0) * BM + lr] : f16x2_scale_of(__uint_as_float(g.amax[(long)b * g.M + row]));
             }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + srow + i * 32 + (r & 3) + 8 * (r >> 2);
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + srow + i * 16 + r;
                 const float sc = rsc[r] * g.sB16;
+                const unsigned o_ = (unsigned)(srow + i * 16 + r) * ldc4 + (unsigned)(wn * 128 + l15) * 4u;
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (row < g.M && n0 + wn * 128 + j * 32 + l31 < g.N) *reinterpret_cast<float *>(Cb + (o_ + 128u * j)) = acc[i][j][r] * sc;
-                o_ += ((r & 3) == 3) ? 5u * ldc4 : ldc4;
+                for (int j = 0; j < 8; ++j)
+                    if (row < g.M && n0 + wn * 128 + j * 16 + l15 < g.N) *reinterpret_cast<float *>(Cb + (o_ + 64u * j)) = acc[i][j][r] * sc;
             }
         }
     }
 }
+#undef CC16_WAITB
 
 // dst[q*plane + i] = fp16 piece q of src[i] * inv (round to nearest), four elements per thread
 __global__ __launch_bounds__(256) void split2h_kernel(const float *__restrict__ src, unsigned short *__restrict__ dst, long n4, long plane,
