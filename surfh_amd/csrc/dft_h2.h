@@ -61,6 +61,7 @@ struct DftH2AdjMix {
     int T = 0, LPt = 0;
     float *mpart = nullptr;                    // work buffer of dft_h2_adjmix_part_floats(LP, hb) floats
     int nslot = 0;                             // set by the launcher
+    int kt0 = 0;                               // the source rows k and Kn - k are zero for k < 16 kt0: those k-steps are skipped
 };
 size_t dft_h2_adjmix_part_floats(long LP, int hb);
 int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjMix &am, float *madj, long PL, long KBP,

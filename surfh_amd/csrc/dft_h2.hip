@@ -383,6 +383,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
     const unsigned c4 = (unsigned)l31 * 4u;
     const int nk = g.KP / BK;
     const int kin = g.Kn / 2 + 1;
+    const int kt0 = am.kt0;            // first k-step whose rows (k or Kn - k) can be non-zero
     // unused by this kernel, referenced by the shared macros
     const float4 *mtab = nullptr;
     const float4 tw = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -473,8 +474,8 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
     int e = 0, en = 0;
 
     H2_LSETUP(tile);
-    H2_LOAD(0);
-    H2_FOLD(0);
+    H2_LOAD(kt0);
+    H2_FOLD(kt0);
     {
         int p;
         H2_MAXEXP_W(p);
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
     }
     split8h(x0, e, c0h, c0l);
     split8h(x1, e, c1h, c1l);
-    H2_LOAD(1);
+    H2_LOAD(kt0 + 1);
     // ---- the OTF stream -----------------------------------------------------------------------------------------
     // The OTF rows of a tile reach the lanes through staging buffers in LDS: three 4 KB slots per wave.  A lane owns ROWS
     // here, so read straight from memory a wave instruction would touch 32 rows x 32 B (measured: 2.3 TB/s).  Instead one
@@ -550,7 +551,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
             _Pragma("unroll") for (int t = 0; t < 4; ++t) M[i_][mir_][t] += ta[t] * z0 + tb[t] * z1;            \
         }                                                                                                       \
     }
-    const bool piped = nk >= 5;        // k-steps 1 .. 3 of the loop below exist
+    const bool piped = nk - kt0 >= 5;  // k-steps kt0 + 1 .. kt0 + 3 of the loop below exist
     while (true) {
         asm volatile("" : "+v"(hv));
 #pragma unroll
@@ -561,7 +562,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
         const bool more = next < tend;
         const int kb = tile / tilesX;
         const long n0 = (long)(tile % tilesX) * TNW;
-        for (int kt = 0; kt + 1 < nk; ++kt) {
+        for (int kt = kt0; kt + 1 < nk; ++kt) {
             H2_MFMA_SW(0, kt, acc1, c0h, c0l);
             H2_FOLD(kt + 1);
             int p;
@@ -569,15 +570,15 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
             en = (p + e > E_LIMIT) ? E_TARGET - p : e;
             const int d = en - e;
             if (piped) {               // wave-uniform; the slots were emptied by the previous tile's epilogue
-                if (kt == 1) { H2_HDMA(0, 0, kb, n0); }
-                else if (kt == 2) { H2_HDMA(1, 1, kb, n0); }
-                else if (kt == 3) { H2_HDMA(2, 2, kb, n0); }
+                if (kt == kt0 + 1) { H2_HDMA(0, 0, kb, n0); }
+                else if (kt == kt0 + 2) { H2_HDMA(1, 1, kb, n0); }
+                else if (kt == kt0 + 3) { H2_HDMA(2, 2, kb, n0); }
             }
             if (kt + 2 < nk) {
                 H2_LOAD(kt + 2);
             } else if (more) {
                 H2_LSETUP(next);
-                H2_LOAD(0);
+                H2_LOAD(kt0);
             }
             split8h(x0, en, c0h, c0l);
             H2_MFMA_SW(1, kt, acc2, c1h, c1l);
@@ -595,11 +596,11 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
         }
         H2_MFMA_SW(0, nk - 1, acc1, c0h, c0l);
         if (more) {
-            H2_FOLD(0);
+            H2_FOLD(kt0);
             int p;
             H2_MAXEXP_W(p);
             en = E_TARGET - p;
-            H2_LOAD(1);
+            H2_LOAD(kt0 + 1);
             split8h(x0, en, c0h, c0l);
         }
         H2_MFMA_SW(1, nk - 1, acc2, c1h, c1l);
@@ -767,6 +768,7 @@ size_t dft_h2_adjmix_part_floats(long LP, int hb) {
 }
 
 int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjMix &am0, float *madj, long PL, long KBP, const unsigned short *img, int kA) {
+    if (am0.kt0 < 0 || (am0.kt0 > 0 && g.KP / BK - am0.kt0 < 2)) return (int)hipErrorInvalidValue;
     if (g.kind != 0 || g.mhat || g.KP % BK || g.KP < 2 * BK || g.KP > KT * BK || g.KP > g.Kn || g.N % 128 || g.batch < 1 || !img || !g.src ||
         !am0.hsrc || !am0.tpl || !am0.mpart || !madj || am0.T < 1 || am0.T > 4 || g.Rn < 32 * 3 + 31 || g.Rn > 255 || g.rvalid < 1 || g.rvalid > 128)
         return (int)hipErrorInvalidValue;

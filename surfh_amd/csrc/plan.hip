@@ -842,6 +842,11 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = null
     if (madj) {
         DftH2AdjMix am;
         am.hsrc = p->sotf; am.ldh = 2 * p->KBP * LP; am.sH = 2 * LP; am.tpl = p->tpl; am.T = p->T; am.LPt = (int)LP; am.mpart = p->adjmix_part;
+        if (sub) {       // rows alpha < a_lo and alpha >= a_hi of the intermediate are zero: leading k-steps (rows k, Na - k) without a non-zero row
+            int kt0 = 0;
+            while (16 * kt0 + 15 < p->a_lo && p->Na - (16 * kt0 + 15) >= p->a_hi && h.KP / 16 - (kt0 + 1) >= 5) ++kt0;
+            am.kt0 = kt0;
+        }
         Prof pr(p, "dft_h2_cols_fwd_adjmix");
         LAUNCH_OK(launch_dft_h2_adjmix(p->stream, h, am, madj, p->PL, p->KBP, p->h2img, p->h2kA[0]));
         return 0;
