@@ -193,6 +193,23 @@ int surfh_mmmg_planes_cb(surfh_plan *plan, const float *y, double mu, double mu_
  * RCCL all-reduce of `q` between surfh_normal_dev and surfh_cg_step_dev).            */
 int surfh_normal_dev(surfh_plan *plan, const float *d_dev, float *q_dev, double mu);          /* q  = mu A^T A d   */
 int surfh_prior_add_dev(surfh_plan *plan, const float *d_dev, float *q_dev, double mu_reg);   /* q += mu_reg L d   */
+/* The same building blocks with the solver's vectors in the Fourier domain of the maps (no transform of the maps, no padding and
+ * no prior kernel inside the iteration: the forward model reads the spectra in the loader of its first transform pass, the
+ * adjoint's last pass writes them).  A vector holds surfh_spec_size() floats: [T][2 (re, im)][KAP][KBP], padding zero, bin
+ * (ka, kb) of the unitary half spectrum (rfft2 / sqrt(Na Nb)) multiplied by sqrt(2) unless the bin is its own conjugate
+ * (kb = 0 or 2 kb = Nb) -- so plain dot products of such vectors equal the dot products of the maps, and the CG recurrences
+ * (surfh_cg_iter_dev ...) run on them unchanged.  The quadratic prior here is the separated circular first differences
+ * (surfh_set_prior 0), diagonal in this basis.  Available where the fused transform passes are (surfh_spec_supported).    */
+int surfh_spec_supported(surfh_plan *plan);                                                    /* 1 / 0 */
+int64_t surfh_spec_size(surfh_plan *plan);
+int surfh_to_spec_dev(surfh_plan *plan, const float *x_dev, float *xt_dev);                    /* maps -> vector */
+int surfh_from_spec_dev(surfh_plan *plan, const float *xt_dev, float *x_dev);                  /* vector -> maps */
+int surfh_forward_spec_dev(surfh_plan *plan, const float *dt_dev, float *y_dev);               /* y = A maps(dt) */
+/* qt = mu spectra(A^T y) (+ mu_reg L dt if dt_dev != NULL: only where qt is not summed over ranks afterwards) */
+int surfh_adjoint_spec_dev(surfh_plan *plan, const float *y_dev, float *qt_dev, double mu, const float *dt_dev, double mu_reg);
+/* qt = mu A^T A dt (+ mu_reg L dt if mu_reg != 0) */
+int surfh_normal_spec_dev(surfh_plan *plan, const float *dt_dev, float *qt_dev, double mu, double mu_reg);
+int surfh_prior_spec_add_dev(surfh_plan *plan, const float *dt_dev, float *qt_dev, double mu_reg);   /* qt += mu_reg L dt */
 /* which quadratic regulariser L the solvers and surfh_prior_add_dev apply (QuadCriterion_MRS's `gradient`, fusion_CT.py:98-106,141-162):
  * 0 = "separated": Dr^T Dr + Dc^T Dc, circular first differences NpDiff_r / NpDiff_c (fusion_CT.py:16-43) -- the default;
  * 1 = "joint": D^T D with D the circular convolution by the 3 x 3 Laplacian (Difference_Operator_Joint, fusion_CT.py:45-62).  */

@@ -49,7 +49,8 @@ EXPORTS = [
     "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev", "surfh_wct_forward", "surfh_wct_adjoint",
     "surfh_wct_fwadj", "surfh_wct_expsol", "surfh_tst_create", "surfh_tst_destroy", "surfh_tst_forward",
     "surfh_tst_adjoint", "surfh_tst_fwadj", "surfh_tst_last_error", "surfh_cg", "surfh_cg_cb", "surfh_mmmg", "surfh_cg_planes", "surfh_mmmg_planes", "surfh_cg_planes_cb", "surfh_mmmg_planes_cb", "surfh_maps_to_cube", "surfh_cube_to_maps", "surfh_normal_dev",
-    "surfh_prior_add_dev", "surfh_set_prior", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_cg_iter_dev", "surfh_residual_dev",
+    "surfh_prior_add_dev", "surfh_spec_supported", "surfh_spec_size", "surfh_to_spec_dev", "surfh_from_spec_dev", "surfh_forward_spec_dev",
+    "surfh_adjoint_spec_dev", "surfh_normal_spec_dev", "surfh_prior_spec_add_dev", "surfh_set_prior", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_cg_iter_dev", "surfh_residual_dev",
     "surfh_cg_begin_dev", "surfh_cg_iter_nosync_dev", "surfh_cg_xupdate_nosync_dev", "surfh_cg_refresh_nosync_dev", "surfh_cg_trace",
     "surfh_profile_enable", "surfh_profile_filter", "surfh_profile_count", "surfh_profile_get", "surfh_profile_reset", "surfh_debug_copy",
     "surfh_debug_dims", "surfh_gemm_selftest",
@@ -100,6 +101,15 @@ def load():
     L.surfh_cube_to_maps.argtypes = [vp, c_double_p, C.c_int32, C.c_int32, c_float_p, c_float_p]
     L.surfh_normal_dev.argtypes = [vp, vp, vp, C.c_double]
     L.surfh_prior_add_dev.argtypes = [vp, vp, vp, C.c_double]
+    L.surfh_spec_supported.argtypes = [vp]
+    L.surfh_spec_size.argtypes = [vp]
+    L.surfh_spec_size.restype = C.c_int64
+    L.surfh_to_spec_dev.argtypes = [vp, vp, vp]
+    L.surfh_from_spec_dev.argtypes = [vp, vp, vp]
+    L.surfh_forward_spec_dev.argtypes = [vp, vp, vp]
+    L.surfh_adjoint_spec_dev.argtypes = [vp, vp, vp, C.c_double, vp, C.c_double]
+    L.surfh_normal_spec_dev.argtypes = [vp, vp, vp, C.c_double, C.c_double]
+    L.surfh_prior_spec_add_dev.argtypes = [vp, vp, vp, C.c_double]
     L.surfh_set_prior.argtypes = [vp, C.c_int32]
     L.surfh_dot_dev.argtypes = [vp, vp, vp, C.c_int64, c_double_p]
     L.surfh_cg_step_dev.argtypes = [vp, vp, vp, vp, vp, C.c_int64, C.c_double, c_double_p]

@@ -49,6 +49,10 @@ struct DftH2Args {
     int T = 0, LP = 0;
     long PL = 0, KBP = 0;
     int mix_l0 = 0;                            // with batch > 1 (a wavelength chunk, batched over kb): first plane of the chunk
+    // mhat given in Parseval-scaled form (the solver's vectors, see surfh_normal_spec_dev): column kb is multiplied by
+    // mhat_self (kb = 0 or 2 kb = mix_Nb: the bin is its own conjugate) or mhat_pair (all others) when the table is built
+    float mhat_self = 1.f, mhat_pair = 1.f;
+    int mix_Nb = 0;
 };
 
 // Fused tail of the adjoint: the kind-0 pass of rfft2 followed, inside the kernel, by
@@ -62,6 +66,12 @@ struct DftH2AdjMix {
     float *mpart = nullptr;                    // work buffer of dft_h2_adjmix_part_floats(LP, hb) floats
     int nslot = 0;                             // set by the launcher
     int kt0 = 0;                               // the source rows k and Kn - k are zero for k < 16 kt0: those k-steps are skipped
+    // output in the solver's Parseval-scaled form, optionally with the quadratic prior added (surfh_normal_spec_dev):
+    // madj[..][ka][kb] = out_self | out_pair (by kb, as above) * sum + prior_mu * (4 - 2 cos(2 pi ka / Na) - 2 cos(2 pi kb / Nb)) * prior_src[..]
+    float out_self = 1.f, out_pair = 1.f;
+    int Nb = 0;
+    const float *prior_src = nullptr;
+    float prior_mu = 0.f;
 };
 size_t dft_h2_adjmix_part_floats(long LP, int hb);
 int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjMix &am, float *madj, long PL, long KBP,

@@ -94,6 +94,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
     {                                                                                                           \
         float4 *mt_ = mixbuf + ((kb_) & 1) * (MIX_ROWS * 2);                                                     \
         const int ne = (g.Kn > g.KP ? g.Kn : g.KP) * 2;                                                         \
+        const float msc_ = ((kb_) == 0 || 2 * (kb_) == g.mix_Nb) ? g.mhat_self : g.mhat_pair;                   \
         for (int e_ = tid; e_ < ne; e_ += NTHREADS) {                                                           \
             const int k = e_ >> 1, tp = e_ & 1;        /* float4 = (re, im) of templates 2 tp and 2 tp + 1 */   \
             float v[4];                                                                                         \
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
                 const int t = 2 * tp + (i >> 1), c = i & 1;                                                     \
                 v[i] = (t < g.T && k < g.Kn) ? g.mhat[((long)t * 2 + c) * g.PL + (long)k * g.KBP + (kb_)] : 0.f; \
             }                                                                                                   \
-            mt_[e_] = make_float4(v[0], v[1], v[2], v[3]);                                                      \
+            mt_[e_] = make_float4(v[0] * msc_, v[1] * msc_, v[2] * msc_, v[3] * msc_);                          \
         }                                                                                                       \
         mtab = mt_;                                                                                             \
         mix_kb = (kb_);                                                                                         \
@@ -636,8 +637,12 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
 // madj[t][c][ka * KBP + kb] = sum over the slots that hold partial sums of kb (fixed order); the padding of the spectrum
 // planes (kb >= hb, ka >= Na) is written as zero, as the separate reduction leaves it
 __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *__restrict__ mpart, float *__restrict__ madj, int nslot,
-                                                                   int T, int Na, int KAP, int hb, long KBP, long PL, int NS, int G, int spk) {
+                                                                   int T, int Na, int KAP, int hb, long KBP, long PL, int NS, int G, int spk,
+                                                                   float out_self, float out_pair, int Nb, const float *__restrict__ prior_src,
+                                                                   float prior_mu) {
     const int kb = blockIdx.x;
+    const float osc = (kb == 0 || 2 * kb == Nb) ? out_self : out_pair;
+    const float pcb = prior_src ? 2.f - 2.f * cospif(2.f * (float)kb / (float)Nb) : 0.f;
     if (kb >= hb) {
         for (int i = threadIdx.x; i < KAP * 8; i += 256) {
             const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
@@ -660,9 +665,13 @@ __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *
         const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
         if (t >= T) continue;
         float s = 0.f;
-        if (row < Na)
+        const long o = ((long)t * 2 + c) * PL + (long)row * KBP + kb;
+        if (row < Na) {
             for (int sl = 0; sl < ns; ++sl) s += mpart[((long)kb * nslot + sl) * (256 * 8) + row * 8 + tc];
-        madj[((long)t * 2 + c) * PL + (long)row * KBP + kb] = s;
+            s *= osc;
+            if (prior_src) s += prior_mu * (pcb + 2.f - 2.f * cospif(2.f * (float)row / (float)Na)) * prior_src[o];
+        }
+        madj[o] = s;
     }
 }
 
@@ -787,7 +796,7 @@ int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjM
     hipLaunchKernelGGL(dft_h2_adjmix_kernel, dim3((unsigned)G), dim3(NTHREADS), ldsb, stream, g, am, reinterpret_cast<const uint4 *>(img), kA, (int)NS);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dft_h2_adjmix_reduce_kernel, dim3((unsigned)KBP), dim3(256), 0, stream, am.mpart, madj, nslot, am.T, g.Rn, (int)(PL / KBP),
-                       g.batch, KBP, PL, (int)NS, G / 2, (int)(g.N / 16 / 8));
+                       g.batch, KBP, PL, (int)NS, G / 2, (int)(g.N / 16 / 8), am.out_self, am.out_pair, am.Nb, am.prior_src, am.prior_mu);
     return (int)hipGetLastError();
 }
 

@@ -70,6 +70,9 @@ int launch_spmm_rows_f16(hipStream_t s, const EllTable &t, const float *src, uns
                          int NP, long K, int LinP);
 int launch_dequant_f16x2(hipStream_t s, const unsigned short *src16, long plane, const float *bscale, float *dst, int NP, long K, int LinP,
                          int nchunk);
+// half spectra [planes][KAP][KBP] <-> the spectral-domain solver's Parseval-scaled form; the quadratic prior on such vectors
+int launch_spec_scale(hipStream_t s, const float *src, float *dst, int planes, long PL, long KBP, int Nb, float f_self, float f_pair);
+int launch_spec_prior_add(hipStream_t s, const float *d, float *q, int planes, int Na, int Nb, long PL, long KBP, float mu_reg);
 long ymat_from_y_waves(int PS, int Ldet, int aout);
 // normal operator: sum of the forward GEMM's K slabs straight into the adjoint GEMM's operand -- the two fp16 pieces of
 // ymat [NP][LdetP] (rows >= nrows and columns >= Ldet zero) with one power-of-two scale per row, rowmax[NP] = max |row| as

@@ -760,6 +760,26 @@ __global__ __launch_bounds__(TPB) void ymat16_from_cpart_kernel(const float *__r
     }
 }
 
+// dst[plane][ka][kb] = src * (f_self if kb = 0 or 2 kb = Nb, else f_pair): spectra <-> the solver's Parseval-scaled form
+__global__ __launch_bounds__(TPB) void spec_scale_kernel(const float *__restrict__ src, float *__restrict__ dst, long PL, int KBP, int Nb, float f_self,
+                                                         float f_pair) {
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= PL) return;
+    const int kb = (int)(i % KBP);
+    const long o = (long)blockIdx.y * PL + i;
+    dst[o] = src[o] * ((kb == 0 || 2 * kb == Nb) ? f_self : f_pair);
+}
+// q += mu_reg (Dr^T Dr + Dc^T Dc) d on half spectra: circular first differences are diagonal in the Fourier domain
+__global__ __launch_bounds__(TPB) void spec_prior_add_kernel(const float *__restrict__ d, float *__restrict__ q, int Na, int Nb, long PL, int KBP,
+                                                             float mu_reg) {
+    const long i = (long)blockIdx.x * TPB + threadIdx.x;
+    if (i >= PL) return;
+    const int kb = (int)(i % KBP), ka = (int)(i / KBP);
+    if (ka >= Na || kb > Nb / 2) return;
+    const long o = (long)blockIdx.y * PL + i;
+    q[o] += mu_reg * (4.f - 2.f * cospif(2.f * (float)ka / (float)Na) - 2.f * cospif(2.f * (float)kb / (float)Nb)) * d[o];
+}
+
 __global__ __launch_bounds__(TPB) void fill_zero_kernel(float *p, long n) {
     long i = (long)blockIdx.x * TPB + threadIdx.x;
     const long stride = (long)gridDim.x * TPB;
@@ -1218,6 +1238,15 @@ int launch_ymat16_from_cpart(hipStream_t s, const float *cpart, long slab, int n
     else if (nv == 3) SURFH_Y16(3);
     else SURFH_Y16(4);
 #undef SURFH_Y16
+    return (int)hipGetLastError();
+}
+
+int launch_spec_scale(hipStream_t s, const float *src, float *dst, int planes, long PL, long KBP, int Nb, float f_self, float f_pair) {
+    hipLaunchKernelGGL(spec_scale_kernel, dim3((unsigned)((PL + TPB - 1) / TPB), planes), dim3(TPB), 0, s, src, dst, PL, (int)KBP, Nb, f_self, f_pair);
+    return (int)hipGetLastError();
+}
+int launch_spec_prior_add(hipStream_t s, const float *d, float *q, int planes, int Na, int Nb, long PL, long KBP, float mu_reg) {
+    hipLaunchKernelGGL(spec_prior_add_kernel, dim3((unsigned)((PL + TPB - 1) / TPB), planes), dim3(TPB), 0, s, d, q, Na, Nb, PL, (int)KBP, mu_reg);
     return (int)hipGetLastError();
 }
 

@@ -162,6 +162,12 @@ struct surfh_plan {
     // intermediate in its own buffer, whose columns outside the range stay zero from plan creation on.
     int a_lo = 0, a_hi = 0, b_lo = 0, b_hi = 0;  // (b: the same for the cube rows beta)
     float *ycol_adj = nullptr;
+    // spectral-domain solver calls (surfh_normal_spec_dev ...): the maps' half spectra in Parseval-scaled form go in and out of the
+    // transform passes directly.  Set for the duration of one call.
+    const float *spec_in = nullptr;              // forward: the mix loader reads this instead of mhat
+    float *spec_out = nullptr;                   // adjoint: the fused tail writes this instead of mhat
+    const float *spec_prior_src = nullptr;       // adjoint: + spec_prior_mu * |D|^2 * this (the quadratic prior, world = 1)
+    float spec_mu = 1.f, spec_prior_mu = 0.f;
     float *adjmix_part = nullptr;                // fused adjoint tail (dft_h2_adjmix_kernel): partial sums per (k_beta, slot); null: off
     int h2kA[3] = {0, 0, 0};
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
@@ -847,6 +853,10 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = null
             while (16 * kt0 + 15 < p->a_lo && p->Na - (16 * kt0 + 15) >= p->a_hi && h.KP / 16 - (kt0 + 1) >= 5) ++kt0;
             am.kt0 = kt0;
         }
+        if (p->spec_out && madj == p->spec_out) {      // the solver's scaled half spectrum, mu and the quadratic prior folded in
+            am.out_self = p->spec_mu; am.out_pair = p->spec_mu * 1.41421356237309505f; am.Nb = p->Nb;
+            am.prior_src = p->spec_prior_src; am.prior_mu = p->spec_prior_mu;
+        }
         Prof pr(p, "dft_h2_cols_fwd_adjmix");
         LAUNCH_OK(launch_dft_h2_adjmix(p->stream, h, am, madj, p->PL, p->KBP, p->h2img, p->h2kA[0]));
         return 0;
@@ -870,6 +880,7 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     g.e[0] = 1.f; g.e[1] = -1.f; g.e[2] = 1.f; g.e[3] = 1.f;
     g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = 1.f; g.e_alt[3] = -1.f;
     if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
+    if (mix && p->spec_in) { g.mhat = p->spec_in; g.mhat_self = 1.f; g.mhat_pair = 0.70710678118654752f; g.mix_Nb = p->Nb; }
     {
         Prof pr(p, mix ? "dft_h2_cols_inv_mix" : "dft_h2_cols_inv");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img, p->h2kA[0]));
@@ -954,7 +965,7 @@ int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, b
 // mhat[t] = sum_l tpl[t][l] conj(sotf[l]) rfft2(cube[l])  (T > 0), or the per-plane product (T == 0)
 // `acols`: the cube is zero outside the alpha range of the channels' tables (the adjoint's accumulator)
 int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
-    if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->mhat, acols);
+    if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->spec_out ? p->spec_out : p->mhat, acols);
     if (rfft2_cube(p, cube, p->spec)) return 1;
     Prof pr(p, "specmix_adj");
     LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->h2));
@@ -965,7 +976,9 @@ int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
 // GEMM operand (fp16 pieces of ymat + row maxima) behind
 int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false) {
     hipStream_t s = p->stream;
-    if (p->T > 0) {
+    if (p->spec_in) {
+        // the maps' spectra are the caller's vector: nothing to transform
+    } else if (p->T > 0) {
         {
             Prof pr(p, "pad_planes");
             LAUNCH_OK(launch_pad_planes(s, x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
@@ -1109,6 +1122,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
         }
     }
     if (adjoint_tail(p, acc, true)) return 1;
+    if (p->spec_out) return 0;         // the caller's vector is the spectrum
     if (p->T > 0) {
         if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
         Prof pr(p, "unpad_planes");
@@ -1753,6 +1767,82 @@ int surfh_prior_add_dev(surfh_plan *p, const float *d, float *q, double mu_reg) 
     LAUNCH_OK(prior_add(p, p->stream, d, q, p->T, (float)mu_reg));
     return 0;
 }
+// ---- the normal operator on the maps' half spectra (the solver's vectors live in the Fourier domain) -------------------------
+// A vector is [T][2 (re, im)][KAP][KBP] floats (padding zero), bin (ka, kb) multiplied by sqrt(2) unless it is its own conjugate
+// (kb = 0, or 2 kb = Nb): the transforms are unitary, so plain dot products of such vectors are the dot products of the maps.
+namespace {
+int spec_check(surfh_plan *p) {
+    if (!p) return fail("null plan");
+    if (!(p->adjmix_part && p->h2 && p->T > 0 && p->fuse_mix && !p->dense_dft && !p->verify))
+        return fail("spectral-domain calls need the fused transform passes (dft_h2 with the fused adjoint tail)");
+    HIP_OK(hipSetDevice(p->dev));
+    return 0;
+}
+struct SpecScope {      // the transient pointers never outlive a call
+    surfh_plan *p;
+    ~SpecScope() { p->spec_in = nullptr; p->spec_out = nullptr; p->spec_prior_src = nullptr; p->spec_mu = 1.f; p->spec_prior_mu = 0.f; }
+};
+}  // namespace
+
+int surfh_spec_supported(surfh_plan *p) {
+    return p && p->adjmix_part && p->h2 && p->T > 0 && p->fuse_mix && !p->dense_dft && !p->verify && p->prior_kind == 0;
+}
+int64_t surfh_spec_size(surfh_plan *p) { return p ? (int64_t)2 * p->T * p->PL : 0; }
+
+// xt = scaled half spectra of the maps x [T][Na][Nb]
+int surfh_to_spec_dev(surfh_plan *p, const float *x, float *xt) {
+    if (spec_check(p)) return 1;
+    hipStream_t s = p->stream;
+    LAUNCH_OK(launch_pad_planes(s, x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
+    LAUNCH_OK(launch_spec_scale(s, p->mhat, xt, 2 * p->T, p->PL, p->KBP, p->Nb, 1.f, 1.41421356237309505f));
+    return 0;
+}
+// x = maps of the scaled half spectra xt
+int surfh_from_spec_dev(surfh_plan *p, const float *xt, float *x) {
+    if (spec_check(p)) return 1;
+    hipStream_t s = p->stream;
+    LAUNCH_OK(launch_spec_scale(s, xt, p->mhat, 2 * p->T, p->PL, p->KBP, p->Nb, 1.f, 0.70710678118654752f));
+    if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
+    LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    return 0;
+}
+// y = A maps(dt)
+int surfh_forward_spec_dev(surfh_plan *p, const float *dt, float *y) {
+    if (spec_check(p)) return 1;
+    SpecScope sc{p};
+    p->spec_in = dt;
+    return forward_dev(p, nullptr, y);
+}
+// qt = mu * spectra(A^T y)  (+ mu_reg * prior(dt) when dt != NULL: only where q is not summed over ranks afterwards)
+int surfh_adjoint_spec_dev(surfh_plan *p, const float *y, float *qt, double mu, const float *dt, double mu_reg) {
+    if (spec_check(p)) return 1;
+    if (dt && p->prior_kind != 0) return fail("the fused spectral prior is the separated first differences");
+    SpecScope sc{p};
+    p->spec_out = qt; p->spec_mu = (float)mu; p->spec_prior_src = dt; p->spec_prior_mu = dt ? (float)mu_reg : 0.f;
+    return adjoint_dev(p, y, nullptr, false);
+}
+// qt = mu * spectra(A^T A maps(dt)) (+ mu_reg * prior(dt) if mu_reg != 0): the CG's normal operator without a single transform
+// of the maps -- no padding, no small DFTs, no prior kernel
+int surfh_normal_spec_dev(surfh_plan *p, const float *dt, float *qt, double mu, double mu_reg) {
+    if (spec_check(p)) return 1;
+    if (mu_reg != 0.0 && p->prior_kind != 0) return fail("the fused spectral prior is the separated first differences");
+    SpecScope sc{p};
+    p->spec_in = dt;
+    p->spec_out = qt; p->spec_mu = (float)mu; p->spec_prior_src = mu_reg != 0.0 ? dt : nullptr; p->spec_prior_mu = (float)mu_reg;
+    static const bool fused = [] { const char *e = getenv("SURFH_NORMAL_FUSED"); return !(e && e[0] == '0'); }();
+    const bool ho = fused && !p->wblur_fp32;
+    if (forward_dev(p, nullptr, p->cg_y, ho)) return 1;
+    return adjoint_dev(p, p->cg_y, nullptr, false, ho);
+}
+// qt += mu_reg * prior(dt) on scaled half spectra (after an all-reduce of qt over ranks)
+int surfh_prior_spec_add_dev(surfh_plan *p, const float *dt, float *qt, double mu_reg) {
+    if (spec_check(p)) return 1;
+    if (p->prior_kind != 0) return fail("the spectral prior is the separated first differences");
+    LAUNCH_OK(launch_spec_prior_add(p->stream, dt, qt, 2 * p->T, p->Na, p->Nb, p->PL, p->KBP, (float)mu_reg));
+    return 0;
+}
+
 int surfh_set_prior(surfh_plan *p, int32_t kind) {
     if (!p) return fail("null plan");
     if (kind != 0 && kind != 1) return fail("prior kind %d: 0 = separated first differences, 1 = joint Laplacian", (int)kind);

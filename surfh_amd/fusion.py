@@ -14,6 +14,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 
 from . import instru
@@ -307,6 +309,13 @@ class DistributedFusion:
             self._sync = lambda: None
             self.model = model_factory(my_ifus, my_pts, my_slices)
         self.n = self.model.isize
+        # The solver's vectors live in the Fourier domain of the maps where the operator offers it (surfh_normal_spec_dev: the
+        # forward model reads the maps' spectra in the loader of its first transform pass, the adjoint's last pass writes them;
+        # no transform of the maps, no padding, no prior kernel inside the iteration).  The basis is orthonormal, so the CG
+        # recurrences and r.r are those of the maps.  SURFH_SPECTRAL_CG=0: vectors are the maps.
+        self.spec = bool(getattr(self.model, "spec_supported", None)) and self.model.spec_supported() and \
+            os.environ.get("SURFH_SPECTRAL_CG", "1") != "0"
+        self.nv = self.model.spec_size if self.spec else self.n      # floats of a solver vector
         self._ytmp = None
         if split == "lambda" and getattr(self, "_band_groups", None):
             idx = np.cumsum([0] + [int(np.prod(c.oshape)) for c in self.model.channels]) if hasattr(self.model, "channels") \
@@ -344,6 +353,23 @@ class DistributedFusion:
 
     def normal(self, d, q, mu, mu_reg):
         """q = mu A^T A d (summed over ranks) + mu_reg (Dr^T Dr + Dc^T Dc) d."""
+        if self.spec:
+            m = self.model
+            if self.group is None:
+                if self.world == 1:
+                    m.normal_spec_dev(d, q, mu, mu_reg)            # prior folded into the adjoint's last kernel
+                    return
+                m.normal_spec_dev(d, q, mu, 0.0)
+            else:                                   # y = sum over the band's lambda parts, then each part's A^T
+                if self._ytmp is None:
+                    self._ytmp = self.torch.empty(m.osize, dtype=self.torch.float32, device=d.device)
+                m.forward_spec_dev(d, self._ytmp)
+                self._reduce_shared(self._ytmp)
+                m.adjoint_spec_dev(self._ytmp, q, mu)
+            self._allreduce(q)
+            if mu_reg:
+                m.prior_spec_add_dev(d, q, mu_reg)
+            return
         if self.group is None:
             self.model.normal_dev(d, q, mu)
         else:                                       # y = sum over the band's lambda parts, then each part's A^T
@@ -364,25 +390,43 @@ class DistributedFusion:
         self._nosync = hasattr(m, "cg_iter_nosync_dev")          # the HIP operator keeps the CG scalars on the device
         with self._ctx():
             shape = m.ishape
-            self.x = torch.zeros(shape, dtype=torch.float32, device=dev) if x0 is None else \
-                torch.as_tensor(np.ascontiguousarray(x0, dtype=np.float32), device=dev).clone()
-            self.b = torch.empty_like(self.x)
-            self.q = torch.empty_like(self.x)
-            m.adjoint_dev(y, self.b)
-            if mu != 1.0:
-                self.b *= mu
+            if self.spec:
+                self.x = torch.zeros(self.nv, dtype=torch.float32, device=dev)
+                if x0 is not None:
+                    m.to_spec_dev(torch.as_tensor(np.ascontiguousarray(x0, dtype=np.float32), device=dev), self.x)
+                self.b = torch.empty_like(self.x)
+                self.q = torch.empty_like(self.x)
+                m.adjoint_spec_dev(y, self.b, mu)
+            else:
+                self.x = torch.zeros(shape, dtype=torch.float32, device=dev) if x0 is None else \
+                    torch.as_tensor(np.ascontiguousarray(x0, dtype=np.float32), device=dev).clone()
+                self.b = torch.empty_like(self.x)
+                self.q = torch.empty_like(self.x)
+                m.adjoint_dev(y, self.b)
+                if mu != 1.0:
+                    self.b *= mu
             self._allreduce(self.b)
             self.normal(self.x, self.q, mu, mu_reg)
             self.r = self.b - self.q
             self.d = self.r.clone()
             if self._nosync:
-                m.cg_begin_dev(self.r, self.n)
+                m.cg_begin_dev(self.r, self.nv)
                 self._trace = None
             else:
-                self.rr = m.dot_dev(self.r, self.r, self.n)
+                self.rr = m.dot_dev(self.r, self.r, self.nv)
                 self._trace = [self.rr]
         self.mu, self.mu_reg = mu, mu_reg
         self.it = 0
+
+    def x_maps(self):
+        """The current iterate as maps [T, Na, Nb] (a device tensor), whatever basis the solver's vectors live in."""
+        if not self.spec:
+            return self.x
+        with self._ctx():
+            out = self.torch.empty(self.model.ishape, dtype=self.torch.float32, device=self.x.device)
+            self.model.from_spec_dev(self.x, out)
+        self._sync()
+        return out
 
     @property
     def grad_norm(self):
@@ -399,18 +443,18 @@ class DistributedFusion:
             self.normal(self.d, self.q, self.mu, self.mu_reg)
             if self._nosync:
                 if fresh:           # residual recomputed from scratch
-                    m.cg_xupdate_nosync_dev(self.x, self.d, self.q, self.n)
+                    m.cg_xupdate_nosync_dev(self.x, self.d, self.q, self.nv)
                     self.normal(self.x, self.q, self.mu, self.mu_reg)
-                    m.cg_refresh_nosync_dev(self.r, self.b, self.q, self.d, self.n)
+                    m.cg_refresh_nosync_dev(self.r, self.b, self.q, self.d, self.nv)
                 else:
-                    m.cg_iter_nosync_dev(self.x, self.r, self.d, self.q, self.n)
+                    m.cg_iter_nosync_dev(self.x, self.r, self.d, self.q, self.nv)
             else:
-                rr_new = m.cg_step_dev(self.x, self.r, self.d, self.q, self.n, self.rr)
+                rr_new = m.cg_step_dev(self.x, self.r, self.d, self.q, self.nv, self.rr)
                 if fresh:
                     self.normal(self.x, self.q, self.mu, self.mu_reg)
-                    m.residual_dev(self.r, self.b, self.q, self.n)
-                    rr_new = m.dot_dev(self.r, self.r, self.n)
-                m.cg_dir_dev(self.d, self.r, self.n, rr_new / self.rr)
+                    m.residual_dev(self.r, self.b, self.q, self.nv)
+                    rr_new = m.dot_dev(self.r, self.r, self.nv)
+                m.cg_dir_dev(self.d, self.r, self.nv, rr_new / self.rr)
                 self.rr = rr_new
                 self._trace.append(rr_new)
         self.it += 1
@@ -426,5 +470,5 @@ class DistributedFusion:
                     break
         self._sync()
         gn = self.grad_norm
-        return OptimizeResult(x=self.x.cpu().numpy().astype(np.float64), grad_norm=gn, nit=self.it,
+        return OptimizeResult(x=self.x_maps().cpu().numpy().astype(np.float64), grad_norm=gn, nit=self.it,
                               success=bool(np.sqrt(gn[-1]) < self.n * tol))

@@ -226,6 +226,33 @@ class spectroSigRLSCT(LinOp):
     def normal_dev(self, d_t, q_t, mu: float = 1.0):
         _lib.check(self._L.surfh_normal_dev(self._plan, _ptr(d_t), _ptr(q_t), float(mu)))
 
+    # ---- the same with the solver's vectors in the Fourier domain of the maps (include/surfh_amd.h: surfh_normal_spec_dev) ----
+    def spec_supported(self) -> bool:
+        return bool(self._L.surfh_spec_supported(self._plan))
+
+    @property
+    def spec_size(self) -> int:
+        return int(self._L.surfh_spec_size(self._plan))
+
+    def to_spec_dev(self, x_t, xt_t):
+        _lib.check(self._L.surfh_to_spec_dev(self._plan, _ptr(x_t), _ptr(xt_t)))
+
+    def from_spec_dev(self, xt_t, x_t):
+        _lib.check(self._L.surfh_from_spec_dev(self._plan, _ptr(xt_t), _ptr(x_t)))
+
+    def forward_spec_dev(self, dt_t, y_t):
+        _lib.check(self._L.surfh_forward_spec_dev(self._plan, _ptr(dt_t), _ptr(y_t)))
+
+    def adjoint_spec_dev(self, y_t, qt_t, mu: float = 1.0, dt_t=None, mu_reg: float = 0.0):
+        _lib.check(self._L.surfh_adjoint_spec_dev(self._plan, _ptr(y_t), _ptr(qt_t), float(mu), _ptr(dt_t) if dt_t is not None else None,
+                                                  float(mu_reg)))
+
+    def normal_spec_dev(self, dt_t, qt_t, mu: float = 1.0, mu_reg: float = 0.0):
+        _lib.check(self._L.surfh_normal_spec_dev(self._plan, _ptr(dt_t), _ptr(qt_t), float(mu), float(mu_reg)))
+
+    def prior_spec_add_dev(self, dt_t, qt_t, mu_reg: float):
+        _lib.check(self._L.surfh_prior_spec_add_dev(self._plan, _ptr(dt_t), _ptr(qt_t), float(mu_reg)))
+
     def prior_add_dev(self, d_t, q_t, mu_reg: float):
         _lib.check(self._L.surfh_prior_add_dev(self._plan, _ptr(d_t), _ptr(q_t), float(mu_reg)))
 
