@@ -29,7 +29,7 @@ def main():
     same = all(torch.equal(xs[0], t) for t in xs)
     if rank == 0:
         np.savez(os.environ["DIST_OUT"], x=res.x, grad_norm=np.array(res.grad_norm), same=same,
-                 n_groups=len(fus.unit_groups), assignment=np.array(repr(fus.assignment)), nosync=bool(fus._nosync))
+                 n_groups=len(fus.unit_groups), assignment=np.array(repr(fus.assignment)), nosync=bool(fus._nosync), spec=bool(fus.spec))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -64,8 +64,10 @@ class OracleBackedModel:
         r.copy_(b - q)
 
 
-def small_problem():
-    n_pix, lc = 48, 96
+def small_problem(n_pix=None):
+    """``DIST_NPIX`` (or the argument) >= 127 puts the HIP operator on its fused transform passes, i.e. the CG loop in the
+    Fourier domain of the maps (surfh_normal_spec_dev); the default 48 keeps the vectors in the map domain."""
+    n_pix, lc = int(n_pix or os.environ.get("DIST_NPIX", "48")), 96
     wav = np.linspace(7.40, 7.90, lc)
     ax = synth.axes(n_pix)
     mk = lambda fa, fb, ang, ns, R, w, name: instru.IFU(  # noqa: E731

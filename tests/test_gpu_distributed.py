@@ -14,11 +14,15 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,split,refresh", [(2, "lambda", 50), (3, "lambda", 4), (3, "pointing", 50)])
-def test_sharded_cg_on_the_hip_operator(tmp_path, world, split, refresh):
+@pytest.mark.parametrize("world,split,refresh,n_pix", [(2, "lambda", 50, 48), (3, "lambda", 4, 48), (3, "pointing", 50, 48),
+                                                        (2, "lambda", 50, 128), (3, "lambda", 4, 128)],
+                         ids=["w2-lambda", "w3-lambda-refresh4", "w3-pointing", "w2-lambda-spectral", "w3-lambda-refresh4-spectral"])
+def test_sharded_cg_on_the_hip_operator(tmp_path, world, split, refresh, n_pix):
+    """n_pix = 128: the ranks' solver vectors are the maps' scaled half spectra (band sharding: normal_spec + all-reduce +
+    spectral prior; lambda split: forward_spec, group all-reduce of y, adjoint_spec); the reference stays surfh_cg on maps."""
     out = str(tmp_path / "dist.npz")
     iters = 9
-    env = dict(os.environ, DIST_OUT=out, DIST_SPLIT=split, DIST_ITERS=str(iters), DIST_REFRESH=str(refresh),
+    env = dict(os.environ, DIST_OUT=out, DIST_SPLIT=split, DIST_ITERS=str(iters), DIST_REFRESH=str(refresh), DIST_NPIX=str(n_pix),
                MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="2", SURFH_REHEARSAL="1")
     port = 29300 + os.getpid() % 400 + world
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
@@ -26,6 +30,7 @@ def test_sharded_cg_on_the_hip_operator(tmp_path, world, split, refresh):
     subprocess.run(cmd, check=True, env=env, timeout=600, cwd=ROOT)
     got = np.load(out)
     assert bool(got["same"]) and bool(got["nosync"])           # replicated bit-identically; scalars stayed on the device
+    assert bool(got["spec"]) == (n_pix >= 127)
     print(world, split, str(got["assignment"]), "groups on rank 0:", int(got["n_groups"]), flush=True)
     if split == "lambda" and world == 3:
         assert int(got["n_groups"]) >= 1                         # a band is shared: the group-local collective ran
@@ -34,7 +39,7 @@ def test_sharded_cg_on_the_hip_operator(tmp_path, world, split, refresh):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import dist_worker as dw
     from surfh_amd.models import spectroSigRLSCT
-    prob = dw.small_problem()
+    prob = dw.small_problem(n_pix)
     m = spectroSigRLSCT(prob["sotf"], prob["templates"], prob["alpha_axis"], prob["beta_axis"], prob["wavel"], prob["ifus"],
                         prob["step_deg"], prob["pointings"], with_ref=False)
     y = m.forward(prob["maps"])

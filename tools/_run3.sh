@@ -1,5 +1,4 @@
 mkdir -p gpurun_out
-timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/gputests_l.log 2>&1; rc=$?; echo "pytest rc $rc"
-tail -3 gpurun_out/gputests_l.log
-bash tools/_ab.sh SURFH_SPECTRAL_CG=0 SURFH_SPECTRAL_CG=1 SURFH_SPECTRAL_CG=0 SURFH_SPECTRAL_CG=1
+timeout -k 10 900 python -m pytest tests/test_gpu_distributed.py -m gpu -x -q -s > gpurun_out/gputests_m.log 2>&1; rc=$?; echo "pytest rc $rc"
+grep "sharded vs\|passed\|failed\|Error\|error" gpurun_out/gputests_m.log | tail -12
 exit $rc
