@@ -1097,6 +1097,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
         g.A0 = c.ymat; g.lda = c.LdetP;
         g.C = c.Xs; g.ldc = c.K;
         g.M = c.NP; g.N = c.K; g.K = c.LdetP;
+        if (f16) g.K = (c.Ldet + 31) / 32 * 32;      // the columns of ymat beyond Ldet are zero: whole K steps of them are skipped
         {
             Prof pr(p, "gemm_wblur_adj", sB);
             if (p->wblur_fp32) {
@@ -1138,11 +1139,16 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
     return 0;
 }
 
+// the normal operator's two halves exchange the GEMM operands directly (SURFH_NORMAL_FUSED=0: through y)
+bool normal_hand_over(const surfh_plan *p) {
+    static const bool fused = [] { const char *e = getenv("SURFH_NORMAL_FUSED"); return !(e && e[0] == '0'); }();
+    return fused && !p->verify && !p->wblur_fp32;
+}
+
 int normal_dev(surfh_plan *p, const float *d, float *q, double mu) {
     // y is only the hand-over between the two halves: the channels' slab sums go straight into the adjoint's GEMM operands
     // (SURFH_NORMAL_FUSED=0: through y, as forward() + adjoint() do)
-    static const bool fused = [] { const char *e = getenv("SURFH_NORMAL_FUSED"); return !(e && e[0] == '0'); }();
-    const bool ho = fused && !p->verify && !p->wblur_fp32;
+    const bool ho = normal_hand_over(p);
     if (forward_dev(p, d, p->cg_y, ho)) return 1;
     if (adjoint_dev(p, p->cg_y, q, false, ho)) return 1;
     if (mu != 1.0) {
@@ -1830,8 +1836,7 @@ int surfh_normal_spec_dev(surfh_plan *p, const float *dt, float *qt, double mu, 
     SpecScope sc{p};
     p->spec_in = dt;
     p->spec_out = qt; p->spec_mu = (float)mu; p->spec_prior_src = mu_reg != 0.0 ? dt : nullptr; p->spec_prior_mu = (float)mu_reg;
-    static const bool fused = [] { const char *e = getenv("SURFH_NORMAL_FUSED"); return !(e && e[0] == '0'); }();
-    const bool ho = fused && !p->wblur_fp32;
+    const bool ho = normal_hand_over(p);
     if (forward_dev(p, nullptr, p->cg_y, ho)) return 1;
     return adjoint_dev(p, p->cg_y, nullptr, false, ho);
 }
