@@ -158,30 +158,38 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
         }                                                                                                       \
     }
     // fold (and mix) the raw values into the two data streams of k-step kt_
+#define H2_FOLD_BODY(kt_, PV_)                                                                                   \
+        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
+            const int k = (kt_) * BK + 8 * hv + j;                                                              \
+            const bool pv = PV_;                                                                                \
+            float a = xr[j], b = qr[j];                                                                         \
+            if (MIX) {      /* own component of (re + i im) * s: re' = re sr - im si, im' = im sr + re si */       \
+                const float ap = pair_swap(a), bp = pair_swap(b);                                               \
+                const int kp = pv ? g.Kn - k : k;                                                               \
+                /* s = sum_t tw[t] (re, im)[t] as packed pairs: two v_pk_fma_f32 per table float4 */                 \
+                const float4 m01 = mtab[2 * k], m23 = mtab[2 * k + 1], n01 = mtab[2 * kp], n23 = mtab[2 * kp + 1]; \
+                const f32x2 sv = tw.x * f32x2{m01.x, m01.y} + tw.y * f32x2{m01.z, m01.w} + tw.z * f32x2{m23.x, m23.y} + tw.w * f32x2{m23.z, m23.w}; \
+                const f32x2 uv = tw.x * f32x2{n01.x, n01.y} + tw.y * f32x2{n01.z, n01.w} + tw.z * f32x2{n23.x, n23.y} + tw.w * f32x2{n23.z, n23.w}; \
+                a = a * sv[0] + sgv * (ap * sv[1]);                                                             \
+                b = b * uv[0] + sgv * (bp * uv[1]);                                                             \
+            }                                                                                                   \
+            const float ev = a + (pv ? b : 0.f), od = pv ? a - b : 0.f;                                         \
+            x0[j] = ev;                                                                                         \
+            x1[j] = (KIND == 0) ? pair_swap(od) : od;          /* kind 0: the odd part of the other component */   \
+        }
 #define H2_FOLD(kt_)                                                                                            \
     {                                                                                                           \
-        _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                         \
-            if (KIND == 2) {                                                                                    \
+        if (KIND == 2) {                                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                                     \
                 x0[j] = xr[j];                                                                                  \
                 x1[j] = qr[j];                                                                                  \
-            } else {                                                                                            \
-                const int k = (kt_) * BK + 8 * hv + j;                                                          \
-                const bool pv = (k >= 1) && (k < kin) && (2 * k != g.Kn);                                       \
-                float a = xr[j], b = qr[j];                                                                     \
-                if (MIX) {      /* own component of (re + i im) * s: re' = re sr - im si, im' = im sr + re si */   \
-                    const float ap = pair_swap(a), bp = pair_swap(b);                                           \
-                    const int kp = pv ? g.Kn - k : k;                                                           \
-                    /* s = sum_t tw[t] (re, im)[t] as packed pairs: two v_pk_fma_f32 per table float4 */             \
-                    const float4 m01 = mtab[2 * k], m23 = mtab[2 * k + 1], n01 = mtab[2 * kp], n23 = mtab[2 * kp + 1]; \
-                    const f32x2 sv = tw.x * f32x2{m01.x, m01.y} + tw.y * f32x2{m01.z, m01.w} + tw.z * f32x2{m23.x, m23.y} + tw.w * f32x2{m23.z, m23.w}; \
-                    const f32x2 uv = tw.x * f32x2{n01.x, n01.y} + tw.y * f32x2{n01.z, n01.w} + tw.z * f32x2{n23.x, n23.y} + tw.w * f32x2{n23.z, n23.w}; \
-                    a = a * sv[0] + sgv * (ap * sv[1]);                                                         \
-                    b = b * uv[0] + sgv * (bp * uv[1]);                                                         \
-                }                                                                                               \
-                const float ev = a + (pv ? b : 0.f), od = pv ? a - b : 0.f;                                     \
-                x0[j] = ev;                                                                                     \
-                x1[j] = (KIND == 0) ? pair_swap(od) : od;      /* kind 0: the odd part of the other component */   \
             }                                                                                                   \
+        } else if ((kt_) >= 1 && ((kt_) + 1) * BK <= kin && (g.Kn & 1)) {                                       \
+            /* every k of the step has its mirror row (wave-uniform; all but the first and the last step of an odd length): \
+               the same values without the per-element tests */                                                 \
+            H2_FOLD_BODY(kt_, true)                                                                             \
+        } else {                                                                                                \
+            H2_FOLD_BODY(kt_, (k >= 1) && (k < kin) && (2 * k != g.Kn))                                         \
         }                                                                                                       \
     }
     // exponent p of this column's largest folded magnitude (|x| < 2^p), over both streams and both k halves
@@ -683,6 +691,7 @@ __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *
 #undef H2_BLOAD2
 #undef H2_LOAD
 #undef H2_FOLD
+#undef H2_FOLD_BODY
 #undef H2_MAXEXP
 #undef H2_MFMA
 

@@ -18,6 +18,7 @@
 #include "lds_attr.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -64,8 +65,8 @@ __global__ __launch_bounds__(256) void split_rows2h_kernel(const float *__restri
 #ifndef CC_EXP
 #define CC_EXP 0          // experiment mask (tools/exp): 1 no DMA inside the loop, 2 no fragment reads, 4 no MFMAs
 #endif
-constexpr int CC2_MAXSEG = 16;                                        // K segments one slab may cross (launcher checks)
-constexpr size_t LDS2_BYTES = LDS_BYTES + (size_t)CC2_MAXSEG * BM * sizeof(float);
+constexpr int CC2_MAXSEG = 64;                                        // K segments one slab may cross (launcher checks)
+constexpr size_t LDS2_BYTES = LDS_BYTES + (size_t)CC2_MAXSEG * BM;    // the scales are powers of two: one exponent byte each
 
 // a pointer the compiler keeps in scalar registers (wave-uniform by construction)
 __device__ __forceinline__ const char *cc2_uniform(const char *p) {
@@ -83,9 +84,9 @@ __device__ __forceinline__ int cc2_seg_end(int k, int segLinP) {
     const int e1 = col * segLinP + (in / 1024 + 1) * 1024, e2 = (col + 1) * segLinP;
     return __builtin_amdgcn_readfirstlane(e1 < e2 ? e1 : e2);
 }
-// old / new for two power-of-two scales (f16x2_scale_of), exact; exponent difference clamped to the normal range
-__device__ __forceinline__ float cc2_pow2_ratio(float so, float sn) {
-    int e = (int)(__float_as_uint(so) >> 23) - (int)(__float_as_uint(sn) >> 23) + 127;
+// old / new for two power-of-two scales (f16x2_scale_of) given by their exponent fields, exact; difference clamped to the normal range
+__device__ __forceinline__ float cc2_pow2_ratio(unsigned eo, unsigned en) {
+    int e = (int)eo - (int)en + 127;
     e = e < 1 ? 1 : (e > 254 ? 254 : e);
     return __uint_as_float((unsigned)e << 23);
 }
@@ -119,47 +120,63 @@ __device__ __forceinline__ void cc2_dma(const char *base, unsigned off, unsigned
 // data.  The 16x16x32 shape draws less per flop: 0.225 ms on random operands (0.170 on constant ones) -- tools/exp/cc_main.hip.
 typedef float f32x4v __attribute__((ext_vector_type(4)));
 
-template <int U, int N, bool DMA>
+// FAR: a K step whose products are kept as h*h only (see "K-step classes" in front of the kernel): one MFMA per block instead of
+// three, no l fragments, no l pieces in the DMA
+template <int U, int N, bool DMA, bool FAR>
 __device__ __forceinline__ void cc16_slot(f32x4v (&acc)[4][8], f16x8 (&A)[4][2], const f16x8 (&Bc)[2][2], f16x8 (&Bn)[2][2], unsigned ran,
                                           unsigned rbn, const char *ka, const char *kb, long pA2, long pB2, const unsigned (&offA)[2],
                                           const unsigned (&offB)[2], unsigned ls) {
     constexpr int i = N / 6, jj = (N / 3) & 1, j = 2 * U + jj, p = N % 3;
-    if constexpr (!(CC_EXP & 4))
+    if constexpr (!(CC_EXP & 4) && (!FAR || p == 2))
         asm volatile("v_mfma_f32_16x16x32_f16 %0, %1, %2, %0" : "+v"(acc[i][j]) : "v"(A[i][p == 0 ? 1 : 0]), "v"(Bc[jj][p == 1 ? 1 : 0]));
     if constexpr (N < 4 && !(CC_EXP & 2)) {        // B fragments of the next unit (unit 3: of the next K step's unit 0, other stage)
         constexpr int jn = 2 * ((U + 1) & 3) + (N >> 1), q = N & 1;
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Bn[N >> 1][q]) : "v"(rbn), "n"(q * PIECE * 2 + jn * 16 * BK * 2));
+        if constexpr (!FAR || q == 0)
+            asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(Bn[N >> 1][q]) : "v"(rbn), "n"(q * PIECE * 2 + jn * 16 * BK * 2));
     }
     if constexpr (U == 3 && N % 6 == 5 && !(CC_EXP & 2)) {      // row block i is done with its A fragments: the next K step's follow
         asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[i][0]) : "v"(ran), "n"(i * 16 * BK * 2));
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[i][1]) : "v"(ran), "n"(PIECE * 2 + i * 16 * BK * 2));
+        if constexpr (!FAR) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(A[i][1]) : "v"(ran), "n"(PIECE * 2 + i * 16 * BK * 2));
     }
     constexpr int d = (U == 3 && N % 3 != 2 && N < 12) ? N - N / 3 : -1;       // pieces 0..7 behind MFMAs 0, 1, 3, 4, 6, 7, 9, 10
-    if constexpr (DMA && d >= 0 && !(CC_EXP & 1)) {
+    if constexpr (DMA && d >= 0 && !(CC_EXP & 1) && (!FAR || d < 4)) {
         constexpr int q = d >> 2, i2 = (d >> 1) & 1;
         if constexpr (d & 1) cc2_dma(kb + q * pB2, offB[i2], ls + (unsigned)((q * PIECE + (BM + i2 * 128) * BK) * 2));
         else cc2_dma(ka + q * pA2, offA[i2], ls + (unsigned)((q * PIECE + i2 * 128 * BK) * 2));
     }
 }
-template <int U, bool DMA, int N = 0>
+template <int U, bool DMA, bool FAR, int N = 0>
 __device__ __forceinline__ void cc16_unit(f32x4v (&acc)[4][8], f16x8 (&A)[4][2], const f16x8 (&Bc)[2][2], f16x8 (&Bn)[2][2], unsigned ran,
                                           unsigned rbn, const char *ka, const char *kb, long pA2, long pB2, const unsigned (&offA)[2],
                                           const unsigned (&offB)[2], unsigned ls) {
     if constexpr (N < 24) {
-        // unit 0: row block 3's fragments of this K step were requested last in the previous unit 3 (two reads), before this
-        // unit's four B reads: wait for them here
-        if constexpr (U == 0 && N == 18 && !(CC_EXP & 2)) asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(A[3][0]), "+v"(A[3][1]));
-        cc16_slot<U, N, DMA>(acc, A, Bc, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
-        cc16_unit<U, DMA, N + 1>(acc, A, Bc, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
+        // unit 0: row block 3's fragments of this K step were requested last in the previous unit 3 (two reads; one in a FAR step),
+        // before the read of the K-step list entry and this unit's four (two) B reads: wait for them here
+        if constexpr (U == 0 && N == 18 && !(CC_EXP & 2)) {
+            if constexpr (FAR) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(A[3][0]), "+v"(A[3][1]));
+            else asm volatile("s_waitcnt lgkmcnt(5)" : "+v"(A[3][0]), "+v"(A[3][1]));
+        }
+        cc16_slot<U, N, DMA, FAR>(acc, A, Bc, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
+        cc16_unit<U, DMA, FAR, N + 1>(acc, A, Bc, Bn, ran, rbn, ka, kb, pA2, pB2, offA, offB, ls);
     }
 }
 // wait until at most n_ LDS reads of this wave are outstanding (the B fragments of the next unit are operands)
 #define CC16_WAITB(n_, B_)                                                                                              \
     asm volatile("s_waitcnt lgkmcnt(" #n_ ")" : "+v"(B_[0][0]), "+v"(B_[1][0]), "+v"(B_[0][1]), "+v"(B_[1][1]))
 
+// K-step classes.  The constant operand of this path, the spectral response, decays away from its diagonal: for a tile of 256
+// of its rows most K steps hold only the far tails.  The launcher may pass, per tile column, two lists of K steps (klist):
+// "near" steps keep the three products, "far" steps only h*h -- a relative error of 2^-10 at worst on terms whose total weight
+// the host bounded (plan.hip: build_klist; far steps of a row sum to < 2^-8 of its l1 norm and < 2^-10 of its l2 norm).  A far
+// step issues a third of the MFMAs and moves half the operand bytes: 0.44 of the time of a near one (tools/exp/cc_main.hip).
+// Without lists every step of the slab is near, in ascending order.  List entry = K step | segment of A's block scales << 16.
+constexpr int CC2_MAXLIST = 1024;                                     // K steps of one slab (launcher checks)
+constexpr size_t LDS3_BYTES = LDS2_BYTES + (size_t)CC2_MAXLIST * sizeof(int);
+
 __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
-    float *sctab = reinterpret_cast<float *>(lds + 2 * STAGE);
+    unsigned char *sctab = reinterpret_cast<unsigned char *>(lds + 2 * STAGE);     // [segment][256 rows] exponent fields of A's block scales
+    int *klds = reinterpret_cast<int *>(sctab + CC2_MAXSEG * BM);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN, tiles = tilesM * tilesN;
     const long total = (long)tiles * g.splitK * g.batch, per = (total + 7) / 8;
@@ -169,7 +186,38 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     const int tm = t % tilesM, tn = t / tilesM;
     const int b = z / g.splitK, sk = z % g.splitK;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int Kper = g.K / g.splitK, kbeg = sk * Kper, nk = Kper / BK;
+    const float *bs = g.bscale;
+
+    // this slab's K steps: near ones first, then the far ones, each in ascending order
+    int nnear, nfar, seg0 = 0, nseg = 0;
+    if (g.klist) {
+        const int *kl = g.klist + (long)tn * g.klistStride;
+        const int NN = kl[0], NF = kl[1];
+        const int a0 = (int)((long)NN * sk / g.splitK), a1 = (int)((long)NN * (sk + 1) / g.splitK);
+        const int f0 = (int)((long)NF * sk / g.splitK), f1 = (int)((long)NF * (sk + 1) / g.splitK);
+        nnear = __builtin_amdgcn_readfirstlane(a1 - a0);
+        nfar = __builtin_amdgcn_readfirstlane(f1 - f0);
+        for (int e = tid; e < nnear; e += 512) klds[e] = kl[2 + a0 + e];
+        for (int e = tid; e < nfar; e += 512) klds[nnear + e] = kl[2 + NN + f0 + e];
+        if (bs) nseg = (g.K / g.segLinP) * g.segChunks;               // every segment of A (launcher: <= CC2_MAXSEG)
+    } else {
+        const int Kper = g.K / g.splitK, kbeg = sk * Kper;
+        nnear = Kper / BK;
+        nfar = 0;
+        if (bs) {
+            seg0 = cc2_seg_of(kbeg, g.segLinP, g.segChunks);
+            nseg = cc2_seg_of(kbeg + Kper - 1, g.segLinP, g.segChunks) - seg0 + 1;
+        }
+        for (int e = tid; e < nnear; e += 512) {
+            const int k = kbeg + e * BK;
+            klds[e] = (k / BK) | (bs ? ((k / g.segLinP) * g.segChunks + (k % g.segLinP) / 1024) << 16 : 0);
+        }
+    }
+    for (int e = tid; e < nseg * BM; e += 512) {
+        int row = m0 + (e & (BM - 1));
+        row = row < g.M ? row : g.M - 1;
+        sctab[e] = (unsigned char)(__float_as_uint(bs[(long)(seg0 + (e >> 8)) * g.M + row]) >> 23);
+    }
 
     // DMA: LDS slot lane & 3 of row lane >> 2 (of a 16-row group) holds the global chunk (lane & 3) ^ (-(lane >> 4) & 3)
     unsigned offA[2], offB[2];
@@ -185,21 +233,11 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
             offB[i] = (unsigned)(((long)n * g.ldb + 8 * chunk) * 2);
         }
     }
-    const char *baseA = cc2_uniform(reinterpret_cast<const char *>(g.A3 + (long)b * g.sA + kbeg));
-    const char *baseB = cc2_uniform(reinterpret_cast<const char *>(g.B16 + (long)b * g.sB + kbeg));
+    const char *baseA = cc2_uniform(reinterpret_cast<const char *>(g.A3 + (long)b * g.sA));
+    const char *baseB = cc2_uniform(reinterpret_cast<const char *>(g.B16 + (long)b * g.sB));
     const long pA2 = g.pA3 * 2, pB2 = g.pB16 * 2;
     const unsigned ldsw = (unsigned)(size_t)lds + (unsigned)(wave * 16 * BK * 2);
-#define CC_DMA(kt_, st_)                                                                                               \
-    {                                                                                                                  \
-        const char *ka = baseA + (long)(kt_) * (BK * 2), *kb = baseB + (long)(kt_) * (BK * 2);                         \
-        const unsigned ls = ldsw + (unsigned)(st_) * (STAGE * 2);                                                      \
-        _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                                \
-            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
-                cc2_dma(ka + q * pA2, offA[i], ls + (q * PIECE + i * 128 * BK) * 2);                                   \
-                cc2_dma(kb + q * pB2, offB[i], ls + (q * PIECE + (BM + i * 128) * BK) * 2);                            \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
+    const unsigned kaddr = (unsigned)(size_t)klds;
     const int l15 = lane & 15, kc = lane >> 4;
     const int wm = wave >> 1, wn = wave & 1;       // 4 x 2 waves, wave tile 64 x 128
     f32x4v acc[4][8];
@@ -208,87 +246,123 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
     // fragment byte addresses in stage 0 (the stage is toggled by XOR with its size)
-    unsigned ra = (unsigned)(size_t)lds + (unsigned)(((wm * 64 + l15) * BK + ((kc ^ ((-(l15 >> 2)) & 3)) * 8)) * 2);
+    const unsigned ra0 = (unsigned)(size_t)lds + (unsigned)(((wm * 64 + l15) * BK + ((kc ^ ((-(l15 >> 2)) & 3)) * 8)) * 2);
     const unsigned fbd = (unsigned)((BM + wn * 128 - wm * 64) * BK * 2);
-    unsigned rb = ra + fbd;
     const bool active = m0 + wm * 64 < g.M;
-
-    const float *bs = g.bscale;
-    int seg0 = 0, seg = 0, seg_end = 1 << 30;
-    if (bs) {
-        seg0 = seg = cc2_seg_of(kbeg, g.segLinP, g.segChunks);
-        seg_end = cc2_seg_end(kbeg, g.segLinP);
-        const int nseg = cc2_seg_of(kbeg + Kper - 1, g.segLinP, g.segChunks) - seg0 + 1;
-        for (int e = tid; e < nseg * BM; e += 512) {
-            int row = m0 + (e & (BM - 1));
-            row = row < g.M ? row : g.M - 1;
-            sctab[e] = bs[(long)(seg0 + (e >> 8)) * g.M + row];
-        }
-    }
     const int srow = wm * 64 + 4 * kc;             // first of the lane's accumulator rows inside the tile (row block 0)
+    int seg = -1;                                  // segment whose scales the accumulators carry (-1: none yet, they are zero)
 
     f16x8 A[4][2], Bx[2][2], By[2][2];             // A [row block][piece] of the current K step; B [column block][piece] of the even / odd unit
 #define CC_RD(dst_, addr_, off_) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst_) : "v"(addr_), "n"(off_))
-    CC_DMA(0, 0);
-    if (nk > 1) {
-        CC_DMA(1, 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the eight (FAR: four) DMA pieces of K step ks_ into stage st_
+#define CC_DMA(FAR_, ks_, st_)                                                                                         \
+    {                                                                                                                  \
+        const char *ka = baseA + (long)(ks_) * (BK * 2), *kb = baseB + (long)(ks_) * (BK * 2);                         \
+        const unsigned ls = ldsw + (unsigned)(st_) * (STAGE * 2);                                                      \
+        _Pragma("unroll") for (int q = 0; q < ((FAR_) ? 1 : 2); ++q) {                                                 \
+            _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
+                cc2_dma(ka + q * pA2, offA[i], ls + (q * PIECE + i * 128 * BK) * 2);                                   \
+                cc2_dma(kb + q * pB2, offB[i], ls + (q * PIECE + (BM + i * 128) * BK) * 2);                            \
+            }                                                                                                          \
+        }                                                                                                              \
     }
-    __syncthreads();
-    if (!active) {
-        for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            const int kd = kt + 2 < nk ? kt + 2 : nk - 1;
-            CC_DMA(kd, kt & 1);
+    __syncthreads();                               // lists and scales are in LDS
+
+    // one pass over n list entries from klds[lb]
+    auto kloop = [&](auto far_tag, const int lb, const int n) __attribute__((always_inline)) {
+        constexpr bool FAR = decltype(far_tag)::value;
+        if (n <= 0) return;                        // workgroup-uniform
+        int e0 = __builtin_amdgcn_readfirstlane(klds[lb]), e1 = __builtin_amdgcn_readfirstlane(klds[lb + (n > 1 ? 1 : 0)]);
+        unsigned ra = ra0, rb = ra0 + fbd;
+        CC_DMA(FAR, e0 & 0xFFFF, 0);
+        if (n > 1) {
+            CC_DMA(FAR, e1 & 0xFFFF, 1);
+            if (FAR) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        return;
-    }
-    if (!(CC_EXP & 2)) {                           // fragments of stage 0: A, B of unit 0
-#pragma unroll
-        for (int i = 0; i < 4; ++i) { CC_RD(A[i][0], ra, 0 + 0); CC_RD(A[i][1], ra, PIECE * 2); ra += 16 * BK * 2; }
-        ra -= 4 * 16 * BK * 2;
-        CC_RD(Bx[0][0], rb, 0); CC_RD(Bx[1][0], rb, 16 * BK * 2); CC_RD(Bx[0][1], rb, PIECE * 2); CC_RD(Bx[1][1], rb, PIECE * 2 + 16 * BK * 2);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[3][0]),
-                     "+v"(A[3][1]), "+v"(Bx[0][0]), "+v"(Bx[1][0]), "+v"(Bx[0][1]), "+v"(Bx[1][1]));
-    }
-    for (int kt = 0; kt < nk; ++kt) {
-        if (bs && kbeg + kt * BK >= seg_end) {     // workgroup-uniform, once per <= 1024 k
-            const int k = kbeg + kt * BK;
-            const int nseg = cc2_seg_of(k, g.segLinP, g.segChunks);
-            seg_end = cc2_seg_end(k, g.segLinP);
-            CC_MFMA_DRAIN();
-            const float *to = sctab + (seg - seg0) * BM + srow, *tn_ = sctab + (nseg - seg0) * BM + srow;
+        __syncthreads();
+        if (!active) {
+            for (int kt = 0; kt < n; ++kt) {
+                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                const int ed = __builtin_amdgcn_readfirstlane(klds[lb + (kt + 2 < n ? kt + 2 : n - 1)]);
+                CC_DMA(FAR, ed & 0xFFFF, kt & 1);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            return;
+        }
+        if (!(CC_EXP & 2)) {                       // fragments of stage 0: A, B of unit 0
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                const float4 so = *reinterpret_cast<const float4 *>(to + i * 16);
-                const float4 sn4 = *reinterpret_cast<const float4 *>(tn_ + i * 16);
-                const f32x4v rt = {cc2_pow2_ratio(so.x, sn4.x), cc2_pow2_ratio(so.y, sn4.y), cc2_pow2_ratio(so.z, sn4.z), cc2_pow2_ratio(so.w, sn4.w)};
-#pragma unroll
-                for (int j = 0; j < 8; ++j) acc[i][j] *= rt;
-                __builtin_amdgcn_sched_barrier(0);
+                CC_RD(A[i][0], ra, 0 + 0);
+                if (!FAR) CC_RD(A[i][1], ra, PIECE * 2);
+                ra += 16 * BK * 2;
             }
-            seg = nseg;
+            ra -= 4 * 16 * BK * 2;
+            CC_RD(Bx[0][0], rb, 0); CC_RD(Bx[1][0], rb, 16 * BK * 2);
+            if (!FAR) { CC_RD(Bx[0][1], rb, PIECE * 2); CC_RD(Bx[1][1], rb, PIECE * 2 + 16 * BK * 2); }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(A[0][0]), "+v"(A[0][1]), "+v"(A[1][0]), "+v"(A[1][1]), "+v"(A[2][0]), "+v"(A[2][1]), "+v"(A[3][0]),
+                         "+v"(A[3][1]), "+v"(Bx[0][0]), "+v"(Bx[1][0]), "+v"(Bx[0][1]), "+v"(Bx[1][1]));
         }
-        const int k2 = kt + 2 < nk ? kt + 2 : nk - 1;
-        const char *ka2 = baseA + (long)k2 * (BK * 2), *kb2 = baseB + (long)k2 * (BK * 2);
-        const unsigned ls2 = ldsw + (unsigned)(kt & 1) * (STAGE * 2);
-        cc16_unit<0, false>(acc, A, Bx, By, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
-        CC16_WAITB(0, By);
-        cc16_unit<1, false>(acc, A, By, Bx, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
-        CC16_WAITB(0, Bx);
-        cc16_unit<2, false>(acc, A, Bx, By, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
-        CC16_WAITB(0, By);
-        // K step kt + 1 landed; every wave holds the last fragments of stage kt & 1 in registers
-        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        ra ^= STAGE * 2; rb ^= STAGE * 2;
-        // unit 3: reads from the other stage (B of the next unit 0, A of the next K step), DMA of K step kt + 2
-        cc16_unit<3, true>(acc, A, By, Bx, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
-        CC16_WAITB(2, Bx);                         // all but row block 3's two A fragments (awaited inside the next unit 0)
+        for (int kt = 0; kt < n; ++kt) {
+            const int nseg_ = e0 >> 16;
+            if (bs && nseg_ != seg) {              // workgroup-uniform: the accumulators move to the scales of this step's segment
+                if (seg >= 0) {
+                    // the scales are per (row, segment), but neighbouring segments mostly carry the same ones: nothing to do then
+                    const unsigned char *to = sctab + (seg - seg0) * BM + srow, *tn_ = sctab + (nseg_ - seg0) * BM + srow;
+                    unsigned so[4], sn[4];
+                    bool same = true;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        so[i] = *reinterpret_cast<const unsigned *>(to + i * 16);        // rows srow + 16 i + 0..3
+                        sn[i] = *reinterpret_cast<const unsigned *>(tn_ + i * 16);
+                        same = same && so[i] == sn[i];
+                    }
+                    if (__builtin_amdgcn_ballot_w64(!same) != 0ull) {                     // wave-uniform
+                        CC_MFMA_DRAIN();
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const f32x4v rt = {cc2_pow2_ratio(so[i] & 255u, sn[i] & 255u), cc2_pow2_ratio((so[i] >> 8) & 255u, (sn[i] >> 8) & 255u),
+                                               cc2_pow2_ratio((so[i] >> 16) & 255u, (sn[i] >> 16) & 255u), cc2_pow2_ratio(so[i] >> 24, sn[i] >> 24)};
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) acc[i][j] *= rt;
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+                seg = nseg_;
+            }
+            // list entry of K step kt + 2 (the DMA of unit 3): requested here, complete at the wait behind unit 0
+            unsigned ev;
+            asm volatile("ds_read_b32 %0, %1" : "=v"(ev) : "v"(kaddr + 4u * (unsigned)(lb + (kt + 2 < n ? kt + 2 : n - 1))));
+            const char *kz = baseA;                // unit 0 .. 2 issue no DMA
+            const unsigned ls2 = ldsw + (unsigned)(kt & 1) * (STAGE * 2);
+            cc16_unit<0, false, FAR>(acc, A, Bx, By, ra, rb, kz, kz, pA2, pB2, offA, offB, ls2);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(By[0][0]), "+v"(By[1][0]), "+v"(By[0][1]), "+v"(By[1][1]), "+v"(ev));
+            const int e2 = __builtin_amdgcn_readfirstlane((int)ev);
+            const char *ka2 = baseA + (long)(e2 & 0xFFFF) * (BK * 2), *kb2 = baseB + (long)(e2 & 0xFFFF) * (BK * 2);
+            cc16_unit<1, false, FAR>(acc, A, By, Bx, ra, rb, kz, kz, pA2, pB2, offA, offB, ls2);
+            CC16_WAITB(0, Bx);
+            cc16_unit<2, false, FAR>(acc, A, Bx, By, ra, rb, kz, kz, pA2, pB2, offA, offB, ls2);
+            CC16_WAITB(0, By);
+            // K step kt + 1 landed; every wave holds the last fragments of stage kt & 1 in registers
+            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            ra ^= STAGE * 2; rb ^= STAGE * 2;
+            // unit 3: reads from the other stage (B of the next unit 0, A of the next K step), DMA of K step kt + 2
+            cc16_unit<3, true, FAR>(acc, A, By, Bx, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
+            if (FAR) { CC16_WAITB(1, Bx); }        // all but row block 3's A fragments (awaited inside the next unit 0)
+            else { CC16_WAITB(2, Bx); }
+            e0 = e1; e1 = e2;
+        }
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    kloop(std::false_type{}, 0, nnear);
+    if (nfar > 0) {
+        __syncthreads();                           // every wave is done with the stages of the near pass
+        kloop(std::true_type{}, nnear, nfar);
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (!active) return;
     CC_MFMA_DRAIN();
 #undef CC_DMA
 #undef CC_RD
@@ -303,7 +377,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
                 const int lr = srow + i * 16 + r;
                 int row = m0 + lr;
                 row = row < g.M ? row : g.M - 1;
-                rsc[r] = bs ? sctab[(seg - seg0) * BM + lr] : f16x2_scale_of(__uint_as_float(g.amax[(long)b * g.M + row]));
+                rsc[r] = bs ? (seg >= 0 ? __uint_as_float((unsigned)sctab[(seg - seg0) * BM + lr] << 23) : 1.f) : f16x2_scale_of(__uint_as_float(g.amax[(long)b * g.M + row]));
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -370,16 +444,22 @@ int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g) {
     if ((double)(BM + 1) * (double)g.ldc * 4.0 >= 2147483648.0) return (int)hipErrorInvalidValue;
     // the DMA addresses a row by a 32-bit byte offset from the operand's base
     if ((double)g.M * (double)g.lda * 2.0 >= 4294967296.0 || (double)g.N * (double)g.ldb * 2.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
-    if (g.bscale) {            // the scales of the K segments a slab crosses sit in LDS
-        auto seg_of = [&](int k) { return (k / g.segLinP) * g.segChunks + (k % g.segLinP) / 1024; };
+    if (g.klist) {             // every slab may visit every segment; a slab's K steps sit in LDS
+        if (g.batch != 1 || g.klistStride < 2 + g.K / BK || g.K / BK > CC2_MAXLIST || g.K / BK > 0xFFFF) return (int)hipErrorInvalidValue;
+        if (g.bscale && (g.K / g.segLinP) * g.segChunks > CC2_MAXSEG) return (int)hipErrorInvalidValue;
+    } else {
         const int Kper = g.K / g.splitK;
-        for (int sk = 0; sk < g.splitK; ++sk)
-            if (seg_of(sk * Kper + Kper - 1) - seg_of(sk * Kper) + 1 > CC2_MAXSEG) return (int)hipErrorInvalidValue;
+        if (Kper / BK > CC2_MAXLIST || g.K / BK > 0xFFFF) return (int)hipErrorInvalidValue;
+        if (g.bscale) {        // the scales of the K segments a slab crosses sit in LDS
+            auto seg_of = [&](int k) { return (k / g.segLinP) * g.segChunks + (k % g.segLinP) / 1024; };
+            for (int sk = 0; sk < g.splitK; ++sk)
+                if (seg_of(sk * Kper + Kper - 1) - seg_of(sk * Kper) + 1 > CC2_MAXSEG) return (int)hipErrorInvalidValue;
+        }
     }
     const long total = (long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch * g.splitK;
     dim3 grid((unsigned)(8 * ((total + 7) / 8)));
     static unsigned long long attr_done = 0;
-    if (int e = ensure_dynamic_lds(gemm_nt_f16x2_cc_kernel, LDS2_BYTES, attr_done)) return e;
-    hipLaunchKernelGGL(gemm_nt_f16x2_cc_kernel, grid, dim3(512), LDS2_BYTES, stream, g);
+    if (int e = ensure_dynamic_lds(gemm_nt_f16x2_cc_kernel, LDS3_BYTES, attr_done)) return e;
+    hipLaunchKernelGGL(gemm_nt_f16x2_cc_kernel, grid, dim3(512), LDS3_BYTES, stream, g);
     return (int)hipGetLastError();
 }

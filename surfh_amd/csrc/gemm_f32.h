@@ -34,6 +34,11 @@ struct GemmArgs {
     // segment(k) = (k / segLinP) * segChunks + (k % segLinP) / 1024 (what launch_spmm_rows_f16 writes)
     const float *bscale = nullptr;
     int segLinP = 0, segChunks = 0;
+    // optional K-step lists of the two-piece fp16 kernel, one record of klistStride ints per 256-row tile of B:
+    // [n_near, n_far, near steps ascending ..., far steps ascending ...], entry = K step | segment << 16 (segment 0 without
+    // bscale).  Near steps keep three products per element, far steps only the leading one (build_klist, plan.hip)
+    const int *klist = nullptr;
+    int klistStride = 0;
 };
 
 // returns hipError_t as int; name is used by the profiler

@@ -101,6 +101,11 @@ struct Channel {
     unsigned short *Xs16 = nullptr, *ymat16 = nullptr;   // the data operands as fp16 pieces (all-consumer kernel, gemm_cc16.hip)
     float *bscale = nullptr;                        // Xs16's scales, one per (row, K segment): [nbs * ceil(LinP/1024)][NP]
     float sW = 1.f;
+    // K-step classes of the two GEMMs (gemm_cc16.hip, build_klist below): per 256-row tile of W16 / Wt16 the steps that keep
+    // all three products and the steps kept as h*h only; ksteps = (near, far) of the forward, (near, far) of the adjoint
+    int *klF = nullptr, *klA = nullptr;
+    int klFs = 0, klAs = 0;
+    long ksteps[4] = {0, 0, 0, 0};
     unsigned *amax = nullptr;                       // [2][NP] max |row| of the data operands: Xs (forward), ymat (adjoint)
     unsigned *pmax = nullptr;                       // per-wave maxima of the kernel that wrote the operand (reduced into amax)
     DevEll fwd, adjT, adjRef;
@@ -562,6 +567,73 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
     if (!c->bsum) {
         if (dev_alloc(&c->ymat, (size_t)c->NP * c->LdetP)) return 1;
         HIP_OK(hipMemset(c->ymat, 0, (size_t)c->NP * c->LdetP * sizeof(float)));
+    }
+    return 0;
+}
+
+// K-step classes of the two-piece fp16 GEMM for its constant operand B [N][ldb] (host copy; K columns, tiles of 256 rows).
+// A step of 32 columns may be computed from the leading fp16 pieces alone ("far": relative error of its terms <= 2^-10, random
+// sign) when what it contributes is small: per tile the steps are taken in ascending order of their largest share of a row,
+// and moved to the far class as long as, for EVERY row of the tile, the far steps together hold <= tol1 of the row's l1 norm
+// and <= tol2 of its l2 norm.  The error this adds to an output is then <= 2^-10 tol1 of sum |B||x| in the worst case (every
+// rounding error aligned) and ~ 3e-4 tol2 of |B row|_2 |x|_2 for rounding errors of random sign: with tol1 = 2^-8, tol2 = 2^-10
+// 4e-6 and 3e-7 of the row's own scale.  The spectral response (a grating's sinc^2, instru.py psfs) falls off as 1 / x^2 from
+// its diagonal: about two thirds of the steps of a tile qualify.  Record per tile: [n_near, n_far, near..., far...], entry =
+// step | segment << 16 (gemm_f32.h).  Fewer than 8 far steps are not worth the second pass: all near.
+int build_klist(const float *B, int N, int K, long ldb, int segLinP, int segChunks, double tol1, double tol2, std::vector<int> *out,
+                int *stride, long *n_near, long *n_far) {
+    const int nb = K / 32, tilesN = (N + 255) / 256;
+    *stride = 2 + nb;
+    out->assign((size_t)tilesN * *stride, 0);
+    *n_near = *n_far = 0;
+    std::vector<double> l1((size_t)256 * nb), l2((size_t)256 * nb), L1(256), L2(256), c1(256), c2(256), imp(nb);
+    std::vector<int> order(nb);
+    std::vector<char> far(nb);
+    for (int tn = 0; tn < tilesN; ++tn) {
+        const int r0 = tn * 256, nr = std::min(256, N - r0);
+        for (int r = 0; r < nr; ++r) {
+            const float *row = B + (long)(r0 + r) * ldb;
+            double s1 = 0.0, s2 = 0.0;
+            for (int b = 0; b < nb; ++b) {
+                double a1 = 0.0, a2 = 0.0;
+                for (int k = 0; k < 32; ++k) { const double v = row[b * 32 + k]; a1 += std::fabs(v); a2 += v * v; }
+                l1[(size_t)r * nb + b] = a1; l2[(size_t)r * nb + b] = a2;
+                s1 += a1; s2 += a2;
+            }
+            L1[r] = s1; L2[r] = s2;
+        }
+        for (int b = 0; b < nb; ++b) {
+            double m = 0.0;
+            for (int r = 0; r < nr; ++r)
+                if (L1[r] > 0.0) m = std::max(m, std::max(l1[(size_t)r * nb + b] / (L1[r] * tol1), std::sqrt(l2[(size_t)r * nb + b] / L2[r]) / tol2));
+            imp[b] = m;
+            order[b] = b;
+            far[b] = 0;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return imp[a] < imp[b]; });
+        std::fill(c1.begin(), c1.end(), 0.0);
+        std::fill(c2.begin(), c2.end(), 0.0);
+        int nf = 0;
+        for (int i = 0; i < nb; ++i) {
+            const int b = order[i];
+            bool ok = true;
+            for (int r = 0; r < nr && ok; ++r)
+                ok = c1[r] + l1[(size_t)r * nb + b] <= tol1 * L1[r] && c2[r] + l2[(size_t)r * nb + b] <= tol2 * tol2 * L2[r];
+            if (!ok) break;
+            for (int r = 0; r < nr; ++r) { c1[r] += l1[(size_t)r * nb + b]; c2[r] += l2[(size_t)r * nb + b]; }
+            far[b] = 1;
+            ++nf;
+        }
+        if (nf < 8) { std::fill(far.begin(), far.end(), 0); nf = 0; }
+        int *rec = out->data() + (size_t)tn * *stride;
+        rec[0] = nb - nf; rec[1] = nf;
+        int in = 2, ifar = 2 + nb - nf;
+        for (int b = 0; b < nb; ++b) {
+            const int k = b * 32;
+            const int e = b | ((segLinP ? (k / segLinP) * segChunks + (k % segLinP) / 1024 : 0) << 16);
+            if (far[b]) rec[ifar++] = e; else rec[in++] = e;
+        }
+        *n_near += nb - nf; *n_far += nf;
     }
     return 0;
 }
@@ -1039,6 +1111,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false)
                 g.B16 = c.W16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW;
                 g.A3 = c.Xs16; g.pA3 = (long)c.NP * c.K;
                 g.bscale = c.bscale; g.segLinP = c.LinP; g.segChunks = (c.LinP + 1023) / 1024;
+                g.klist = c.klF; g.klistStride = c.klFs;
                 LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
         }
@@ -1108,6 +1181,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
                 g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
                 if (!have16) LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
                 g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
+                g.klist = c.klA; g.klistStride = c.klAs;
                 LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
         }
@@ -1214,6 +1288,8 @@ int surfh_plan_destroy(surfh_plan *p) {
         for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
         hipFree(c.W16);
         hipFree(c.Wt16);
+        hipFree(c.klF);
+        hipFree(c.klA);
         hipFree(c.Xs16);
         hipFree(c.bscale);
         hipFree(c.ymat16);
@@ -1502,6 +1578,18 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             if (dev_upload(&c.bscale, ones)) return bail(1);
             if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
                 return bail(fail("operand split failed"));
+            static const bool far_steps = [] { const char *e = getenv("SURFH_WBLUR_FAR"); return !(e && e[0] == '0'); }();
+            const int segChunks = (c.LinP + 1023) / 1024, KA = (c.Ldet + 31) / 32 * 32;
+            if (far_steps && c.K / 32 <= 1024 && c.nbs * segChunks <= 64 && KA / 32 <= 1024) {
+                std::vector<float> hw((size_t)nw);
+                std::vector<int> kl;
+                if (hipMemcpy(hw.data(), c.W, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return bail(fail("copy failed"));
+                build_klist(hw.data(), c.LdetP, c.K, c.K, c.LinP, segChunks, 1.0 / 256, 1.0 / 1024, &kl, &c.klFs, &c.ksteps[0], &c.ksteps[1]);
+                if (c.ksteps[1] > 0 && dev_upload(&c.klF, kl)) return bail(1);
+                if (hipMemcpy(hw.data(), c.Wt, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return bail(fail("copy failed"));
+                build_klist(hw.data(), c.K, KA, c.LdetP, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &c.klAs, &c.ksteps[2], &c.ksteps[3]);
+                if (c.ksteps[3] > 0 && dev_upload(&c.klA, kl)) return bail(1);
+            }
         }
         if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
         hipMemset(c.Cpart, 0, (size_t)c.splitK * c.LdetP * c.NP * sizeof(float));
@@ -2372,6 +2460,10 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
         }
     } else if (w == "range") {         // cube columns / rows the channels' tables touch: [a_lo, a_hi) x [b_lo, b_hi)
         dims[0] = p->a_lo; dims[1] = p->a_hi; dims[2] = p->b_lo; dims[3] = p->b_hi;
+    } else if (w == "ksteps") {        // (tile, K step) pairs of the spectral-blur GEMMs: near / far of the forward, near / far of the adjoint
+        for (auto &c : p->ch)
+            for (int i = 0; i < 4; ++i) dims[i] += c.ksteps[i];
+        for (int i = 0; i < 4; ++i) dims[i] -= 1;
     } else if (w == "info") {
         dims[0] = p->lo; dims[1] = p->hi; dims[2] = p->Lown; dims[3] = (int64_t)p->segs.size();
     } else {
