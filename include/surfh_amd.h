@@ -261,6 +261,9 @@ int surfh_debug_dims(surfh_plan *plan, const char *which, int64_t dims[4]);
 /* stand-alone fp32 MFMA GEMM self-test hook: C[M][N] = A[M][K] B[K][N] (host buffers) */
 int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split_k,
                         const float *A, const float *B, float *C);
+/* (tile, K step) pairs the last two-piece fp16 self-test (SURFH_SELFTEST_F16X2=2: with K-step lists, as the spectral-blur
+ * GEMMs of a plan) ran with all three products / with the leading product only */
+int surfh_gemm_selftest_ksteps(int64_t near_far[2]);
 
 /* ---- masked linear mixing model (MixingST, surfh/Models/mixing.py:276-337; kernels c_fast_forward_TST,
  * c_fast_adjoint_TST, c_precompute_TST of surfh/ToolsDir/cythons_files.pyx:370-463) ----

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
 #define CC_DMA(FAR_, ks_, st_)                                                                                         \
     {                                                                                                                  \
         const char *ka = baseA + (long)(ks_) * (BK * 2), *kb = baseB + (long)(ks_) * (BK * 2);                         \
-        const unsigned ls = ldsw + (unsigned)(st_) * (STAGE * 2);                                                      \
+        const unsigned ls = ldsw + stofs((FAR_), (st_));                                                               \
         _Pragma("unroll") for (int q = 0; q < ((FAR_) ? 1 : 2); ++q) {                                                 \
             _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                            \
                 cc2_dma(ka + q * pA2, offA[i], ls + (q * PIECE + i * 128 * BK) * 2);                                   \
@@ -266,32 +266,41 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
             }                                                                                                          \
         }                                                                                                              \
     }
+    // byte offset of ring stage s: two stages of both pieces, or (far pass: h pieces only) four stages in the same 128 KB --
+    // far stage s takes the place of piece s & 1 of stage s >> 1
+    auto stofs = [](bool far, int s) __attribute__((always_inline)) {
+        return far ? (unsigned)((s >> 1) * (STAGE * 2) + (s & 1) * (PIECE * 2)) : (unsigned)(s * (STAGE * 2));
+    };
     __syncthreads();                               // lists and scales are in LDS
 
     // one pass over n list entries from klds[lb]
+    // A ring of D stages: the DMA of K step kt + D is issued in step kt (unit 3, into the stage step kt has just left) and must
+    // have landed at the barrier of step kt + D - 1.  A near step lasts about 2.5 us, a far one 1 us -- less than a trip to
+    // memory, so the far pass runs four stages deep.
     auto kloop = [&](auto far_tag, const int lb, const int n) __attribute__((always_inline)) {
         constexpr bool FAR = decltype(far_tag)::value;
+        constexpr int D = FAR ? 4 : 2;             // ring depth; a step's DMA group is 4 (far) or 8 instructions
         if (n <= 0) return;                        // workgroup-uniform
-        int e0 = __builtin_amdgcn_readfirstlane(klds[lb]), e1 = __builtin_amdgcn_readfirstlane(klds[lb + (n > 1 ? 1 : 0)]);
-        unsigned ra = ra0, rb = ra0 + fbd;
-        CC_DMA(FAR, e0 & 0xFFFF, 0);
-        if (n > 1) {
-            CC_DMA(FAR, e1 & 0xFFFF, 1);
-            if (FAR) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int e[D];
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+            e[s] = __builtin_amdgcn_readfirstlane(klds[lb + (s < n ? s : n - 1)]);
+            CC_DMA(FAR, e[s] & 0xFFFF, s);
         }
+        if (FAR) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         __syncthreads();
         if (!active) {
             for (int kt = 0; kt < n; ++kt) {
-                asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-                const int ed = __builtin_amdgcn_readfirstlane(klds[lb + (kt + 2 < n ? kt + 2 : n - 1)]);
-                CC_DMA(FAR, ed & 0xFFFF, kt & 1);
+                if (FAR) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                const int ed = __builtin_amdgcn_readfirstlane(klds[lb + (kt + D < n ? kt + D : n - 1)]);
+                CC_DMA(FAR, ed & 0xFFFF, kt & (D - 1));
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             return;
         }
+        unsigned ra = ra0, rb = ra0 + fbd;
         if (!(CC_EXP & 2)) {                       // fragments of stage 0: A, B of unit 0
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -306,7 +315,7 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
                          "+v"(A[3][1]), "+v"(Bx[0][0]), "+v"(Bx[1][0]), "+v"(Bx[0][1]), "+v"(Bx[1][1]));
         }
         for (int kt = 0; kt < n; ++kt) {
-            const int nseg_ = e0 >> 16;
+            const int nseg_ = e[0] >> 16;
             if (bs && nseg_ != seg) {              // workgroup-uniform: the accumulators move to the scales of this step's segment
                 if (seg >= 0) {
                     // the scales are per (row, segment), but neighbouring segments mostly carry the same ones: nothing to do then
@@ -333,27 +342,34 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
                 }
                 seg = nseg_;
             }
-            // list entry of K step kt + 2 (the DMA of unit 3): requested here, complete at the wait behind unit 0
+            // list entry of K step kt + D (the DMA of unit 3): requested here, complete at the wait behind unit 0
             unsigned ev;
-            asm volatile("ds_read_b32 %0, %1" : "=v"(ev) : "v"(kaddr + 4u * (unsigned)(lb + (kt + 2 < n ? kt + 2 : n - 1))));
+            asm volatile("ds_read_b32 %0, %1" : "=v"(ev) : "v"(kaddr + 4u * (unsigned)(lb + (kt + D < n ? kt + D : n - 1))));
             const char *kz = baseA;                // unit 0 .. 2 issue no DMA
-            const unsigned ls2 = ldsw + (unsigned)(kt & 1) * (STAGE * 2);
+            const unsigned ls2 = ldsw + stofs(FAR, kt & (D - 1));
             cc16_unit<0, false, FAR>(acc, A, Bx, By, ra, rb, kz, kz, pA2, pB2, offA, offB, ls2);
             asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(By[0][0]), "+v"(By[1][0]), "+v"(By[0][1]), "+v"(By[1][1]), "+v"(ev));
-            const int e2 = __builtin_amdgcn_readfirstlane((int)ev);
-            const char *ka2 = baseA + (long)(e2 & 0xFFFF) * (BK * 2), *kb2 = baseB + (long)(e2 & 0xFFFF) * (BK * 2);
+            const int en = __builtin_amdgcn_readfirstlane((int)ev);
+            const char *ka2 = baseA + (long)(en & 0xFFFF) * (BK * 2), *kb2 = baseB + (long)(en & 0xFFFF) * (BK * 2);
             cc16_unit<1, false, FAR>(acc, A, By, Bx, ra, rb, kz, kz, pA2, pB2, offA, offB, ls2);
             CC16_WAITB(0, Bx);
             cc16_unit<2, false, FAR>(acc, A, Bx, By, ra, rb, kz, kz, pA2, pB2, offA, offB, ls2);
             CC16_WAITB(0, By);
-            // K step kt + 1 landed; every wave holds the last fragments of stage kt & 1 in registers
-            asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            ra ^= STAGE * 2; rb ^= STAGE * 2;
-            // unit 3: reads from the other stage (B of the next unit 0, A of the next K step), DMA of K step kt + 2
+            // K step kt + 1 landed (younger DMA groups may still be in flight); every wave holds the last fragments of this
+            // step's stage in registers
+            if (FAR) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            {
+                const unsigned nx = stofs(FAR, (kt + 1) & (D - 1));
+                ra = ra0 + nx; rb = ra0 + fbd + nx;
+            }
+            // unit 3: reads from the next stage (B of the next unit 0, A of the next K step), DMA of K step kt + D
             cc16_unit<3, true, FAR>(acc, A, By, Bx, ra, rb, ka2, kb2, pA2, pB2, offA, offB, ls2);
             if (FAR) { CC16_WAITB(1, Bx); }        // all but row block 3's A fragments (awaited inside the next unit 0)
             else { CC16_WAITB(2, Bx); }
-            e0 = e1; e1 = e2;
+#pragma unroll
+            for (int s = 0; s + 1 < D; ++s) e[s] = e[s + 1];
+            e[D - 1] = en;
         }
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };

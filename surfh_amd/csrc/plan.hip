@@ -2494,6 +2494,12 @@ int64_t surfh_debug_copy(surfh_plan *p, const char *which, float *out, int64_t c
     return n;
 }
 
+static long g_selftest_ksteps[2] = {0, 0};
+int surfh_gemm_selftest_ksteps(int64_t near_far[2]) {
+    near_far[0] = g_selftest_ksteps[0]; near_far[1] = g_selftest_ksteps[1];
+    return 0;
+}
+
 int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t split_k, const float *A,
                         const float *B, float *C) {
     HIP_OK(hipSetDevice(device));
@@ -2509,7 +2515,7 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
     g.M = M; g.N = N; g.K = K; g.splitK = sk; g.sCsplit = (long)M * N;
     int rc;
     const char *mode = getenv("SURFH_SELFTEST_F16X2");
-    if (mode && mode[0] == '1') {
+    if (mode && (mode[0] == '1' || mode[0] == '2')) {
         // two-piece fp16 kernel, NT form: B is handed over as [K][N]; transpose it on the host into [N][K]
         std::vector<float> bt((size_t)N * K);
         for (int k = 0; k < K; ++k)
@@ -2534,8 +2540,17 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
         rc = launch_split2h(nullptr, dB, dB16, (long)bt.size(), (long)bt.size(), g.sB16);
         if (rc == 0) rc = launch_split_rows2h(nullptr, dA, dmax, dA16, M, K, (long)M * K);
         g.A3 = dA16; g.pA3 = (long)M * K;
+        int *dkl = nullptr;
+        g_selftest_ksteps[0] = g_selftest_ksteps[1] = 0;
+        if (mode[0] == '2') {      // with K-step lists, classes and tolerances as at plan creation
+            std::vector<int> kl;
+            build_klist(bt.data(), N, K, K, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &g.klistStride, &g_selftest_ksteps[0], &g_selftest_ksteps[1]);
+            if (dev_upload(&dkl, kl)) return 1;
+            g.klist = dkl;
+        }
         if (rc == 0) rc = launch_gemm_nt_f16x2_cc(nullptr, g);
         if (rc == 0) rc = (int)hipDeviceSynchronize();
+        hipFree(dkl);
         hipFree(dB16);
         hipFree(dmax);
         hipFree(dA16);

@@ -92,6 +92,49 @@ def test_gemm_two_piece_fp16_selftest():
         os.environ.pop("SURFH_SELFTEST_F16X2")
 
 
+def test_gemm_two_piece_fp16_k_step_classes():
+    """The same kernel with K-step lists (gemm_cc16.hip "K-step classes"; plan.hip build_klist with the plan's tolerances): a
+    constant operand shaped like the spectral response -- sinc^2 around a diagonal, rows normalised, several beta columns side by
+    side -- has most of its K steps in the far class (leading fp16 product only); the result stays at the error of the
+    three-product kernel.  An operand without structure gets no far steps and runs through the list path unchanged.  Split K
+    divides both lists among the slabs."""
+    from surfh_amd import _lib
+    import ctypes
+    L = _lib.load()
+    rng = np.random.default_rng(3)
+    os.environ["SURFH_SELFTEST_F16X2"] = "2"
+    try:
+        ks = (ctypes.c_int64 * 2)()
+        for (M, N, Lin, ncol, sk) in [(256, 1024, 1152, 2, 1), (384, 1408, 1152, 3, 2), (128, 640, 704, 1, 1)]:
+            K = ncol * Lin
+            lo, li = np.arange(N)[:, None], np.arange(Lin)[None, :]
+            cols = []
+            for c in range(ncol):
+                z = (li - (lo * (Lin / N) + 3.0 * c)) / 2.3
+                w = np.sinc(z) ** 2
+                cols.append(w / w.sum(axis=1, keepdims=True))
+            W = np.concatenate(cols, axis=1)                               # [N][K]
+            B = np.ascontiguousarray(W.T).astype(np.float32)               # the hook takes B as [K][N]
+            for name, A in (("nonneg", rng.random((M, K)) * 50 + 1), ("randn", rng.standard_normal((M, K)))):
+                A = A.astype(np.float32)
+                Cg = np.empty((M, N), dtype=np.float32)
+                _lib.check(L.surfh_gemm_selftest(0, M, N, K, sk, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
+                L.surfh_gemm_selftest_ksteps(ks)
+                e = rel(Cg, A.astype(np.float64) @ B.astype(np.float64))
+                note("gemm_f16x2_klist", M=M, N=N, K=K, sk=sk, data=name, near=int(ks[0]), far=int(ks[1]), err=e)
+                assert ks[1] > ks[0] and e < 1e-6, (M, N, K, sk, name, list(ks), e)
+        M, N, K = 256, 384, 1056
+        A = rng.standard_normal((M, K)).astype(np.float32)
+        B = rng.standard_normal((K, N)).astype(np.float32)
+        Cg = np.empty((M, N), dtype=np.float32)
+        _lib.check(L.surfh_gemm_selftest(0, M, N, K, 3, _lib.fptr(A), _lib.fptr(B), _lib.fptr(Cg)))
+        L.surfh_gemm_selftest_ksteps(ks)
+        e = rel(Cg, A.astype(np.float64) @ B.astype(np.float64))
+        assert ks[1] == 0 and e < 5e-7, (list(ks), e)
+    finally:
+        os.environ.pop("SURFH_SELFTEST_F16X2")
+
+
 @pytest.fixture(scope="module")
 def c1():
     cfg = problems.config1()

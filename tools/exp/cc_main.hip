@@ -45,6 +45,20 @@ static int run(int M, int N, int K, int sk, const char *name) {
     GemmArgs g;
     g.lda = K; g.ldb = K; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K; g.splitK = sk; g.sCsplit = (long)M * N;
     g.B16 = dB16; g.pB16 = (long)B.size(); g.sB16 = sB; g.amax = dmax; g.A3 = dA16; g.pA3 = (long)A.size();
+    // CC_FARFRAC=f: K-step lists with the last fraction f of every tile's steps in the far class (one product): timing of
+    // mixed passes; the error then shows what single fp16 products cost on operands without structure
+    int *dkl = nullptr;
+    if (const char *ff = getenv("CC_FARFRAC")) {
+        const int nb = K / 32, tilesN = (N + 255) / 256, stride = 2 + nb, nf = (int)(atof(ff) * nb);
+        std::vector<int> kl((size_t)tilesN * stride);
+        for (int t = 0; t < tilesN; ++t) {
+            kl[(size_t)t * stride] = nb - nf; kl[(size_t)t * stride + 1] = nf;
+            for (int b = 0; b < nb; ++b) kl[(size_t)t * stride + 2 + b] = b;
+        }
+        CK(hipMalloc(&dkl, kl.size() * 4));
+        CK(hipMemcpy(dkl, kl.data(), kl.size() * 4, hipMemcpyHostToDevice));
+        g.klist = dkl; g.klistStride = stride;
+    }
     CK(hipMemset(dC, 0xFF, (size_t)sk * M * N * 4));
     int rc = launch_gemm_nt_f16x2_cc(st, g);
     if (rc) { printf("launch rc %d\n", rc); return 1; }
@@ -69,7 +83,7 @@ static int run(int M, int N, int K, int sk, const char *name) {
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
     printf("%-8s M=%d N=%d K=%d sk=%d  rel L2 err %.3g (worst abs %.3g)  %.4f ms  %.1f TF/s fp32-equivalent, %.0f TF/s fp16 issued\n", name, M, N, K, sk,
            std::sqrt(num / den), worst, ms, 2.0 * M * N * K / ms * 1e-9, 6.0 * M * N * K / ms * 1e-9);
-    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dB16); hipFree(dmax); hipFree(dA16);
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(dB16); hipFree(dmax); hipFree(dA16); hipFree(dkl);
     return 0;
 }
 
