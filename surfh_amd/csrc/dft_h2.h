@@ -53,6 +53,10 @@ struct DftH2Args {
     // mhat_self (kb = 0 or 2 kb = mix_Nb: the bin is its own conjugate) or mhat_pair (all others) when the table is built
     float mhat_self = 1.f, mhat_pair = 1.f;
     int mix_Nb = 0;
+    // optional list of the super-tiles (8 wave tiles = 128 columns, numbered batch-major) to transform, ascending; the others
+    // are left alone (the forward model's complex pass: the (k_beta, wavelength chunk) pairs outside the OTF's support)
+    const int *vlist = nullptr;
+    int nvalid = 0;
 };
 
 // Fused tail of the adjoint: the kind-0 pass of rfft2 followed, inside the kernel, by
@@ -72,8 +76,13 @@ struct DftH2AdjMix {
     int Nb = 0;
     const float *prior_src = nullptr;
     float prior_mu = 0.f;
+    // optional: only the super-tiles (8 tiles = 128 wavelengths of one k_beta; index k_beta * (LP / 128) + chunk) of `vlist`
+    // (ascending, nvalid entries) are transformed -- the others lie outside the OTF's support and add nothing;
+    // kbstart[kb] = position in vlist of the first super-tile of kb (hb + 1 entries)
+    const int *vlist = nullptr, *kbstart = nullptr;
+    int nvalid = 0;
 };
-size_t dft_h2_adjmix_part_floats(long LP, int hb);
+size_t dft_h2_adjmix_part_floats(long LP, int hb, long nvalid = 0);
 int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjMix &am, float *madj, long PL, long KBP,
                          const unsigned short *img, int kA);
 

@@ -235,8 +235,12 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
     // step's raw values, loads of the step after that, the first stream's fragments rebuilt in place, MFMAs of the
     // second matrix, the second stream's fragments rebuilt.  At a tile seam the next tile's first two k-steps are
     // requested before the stores of the epilogue.
-    int tile = NWAVES * s0 + wave;
-    const int tend = tile + NWAVES * ntw;              // this wave's tiles: tile, tile + 8, ... < tend
+    // tiles are counted in the launch's own numbering vt (super-tile, wave); with a list of super-tiles the real tile follows from it
+    const int *vl = g.vlist;
+#define H2_RT(vt_) (vl ? NWAVES * vl[(vt_) >> 3] + ((vt_) & 7) : (vt_))
+    int vt = NWAVES * s0 + wave;
+    const int vtend = vt + NWAVES * ntw;               // this wave's tiles: vt, vt + 8, ... < vtend
+    int tile = H2_RT(vt);
     int e = 0, en = 0;                                  // block exponents of the current / next k-step's column
 
     H2_LSETUP(tile);
@@ -257,8 +261,8 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
-        const int next = tile + NWAVES;
-        const bool more = next < tend;
+        const bool more = vt + NWAVES < vtend;
+        const int next = more ? H2_RT(vt + NWAVES) : tile;
         for (int kt = 0; kt + 1 < nk; ++kt) {
             H2_MFMA(0, kt, acc1, c0h, c0l);
             H2_FOLD(kt + 1);           // raw holds k-step kt + 1 of this tile
@@ -334,6 +338,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
         if (!more) break;
         e = en;
         tile = next;
+        vt += NWAVES;
     }
 }
 
@@ -452,9 +457,9 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
     // lanes 0-31 store [row][t][c]
 #define H2_FLUSH(kb_)                                                                                           \
     {                                                                                                           \
-        const long spk = tilesX / 8;                   /* super-tiles per k_beta */                              \
+        const long kbs_ = am.kbstart ? (long)am.kbstart[kb_] : (long)(kb_) * (tilesX / 8);   /* first super-tile of kb in the launch's numbering */ \
         int bf = vb;                                                                                            \
-        while (bf > 0 && (long)NS * bf / VP > (long)(kb_) * spk) --bf;            /* first pair that holds tiles of kb */ \
+        while (bf > 0 && (long)NS * bf / VP > kbs_) --bf;                         /* first pair that holds tiles of kb */ \
         const int slot = (vb - bf) * 8 + cs;                                                                    \
         float *mp = am.mpart + ((long)(kb_) * am.nslot + slot) * (256 * 8);                                     \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
@@ -478,8 +483,11 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
             }                                                                                                   \
     }
 
-    int tile = 8 * s0 + cs;
-    const int tend = tile + 8 * ntw;
+    const int *avl = am.vlist;
+#define H2_ART(vt_) (avl ? 8 * avl[(vt_) >> 3] + ((vt_) & 7) : (vt_))
+    int vt = 8 * s0 + cs;
+    const int vtend = vt + 8 * ntw;
+    int tile = H2_ART(vt);
     int e = 0, en = 0;
 
     H2_LSETUP(tile);
@@ -567,8 +575,8 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
-        const int next = tile + 8;
-        const bool more = next < tend;
+        const bool more = vt + 8 < vtend;
+        const int next = more ? H2_ART(vt + 8) : tile;
         const int kb = tile / tilesX;
         const long n0 = (long)(tile % tilesX) * TNW;
         for (int kt = kt0; kt + 1 < nk; ++kt) {
@@ -634,7 +642,9 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
         if (!more) break;
         e = en;
         tile = next;
+        vt += 8;
     }
+#undef H2_ART
 #undef H2_HDMA
 #undef H2_HBLOCK
 #undef H2_MFMA_SW
@@ -647,7 +657,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_adjmix_kernel(DftH2Args g, Df
 __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *__restrict__ mpart, float *__restrict__ madj, int nslot,
                                                                    int T, int Na, int KAP, int hb, long KBP, long PL, int NS, int G, int spk,
                                                                    float out_self, float out_pair, int Nb, const float *__restrict__ prior_src,
-                                                                   float prior_mu) {
+                                                                   float prior_mu, const int *__restrict__ kbstart) {
     const int kb = blockIdx.x;
     const float osc = (kb == 0 || 2 * kb == Nb) ? out_self : out_pair;
     const float pcb = prior_src ? 2.f - 2.f * cospif(2.f * (float)kb / (float)Nb) : 0.f;
@@ -659,8 +669,8 @@ __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *
         return;
     }
     int bf = 0, bl = G - 1;      // pairs bf .. bl of the pass hold tiles of kb: range of pair b = [NS b / G, NS (b + 1) / G)
-    {
-        const long lo = (long)kb * spk, hi = lo + spk;
+    const long lo = kbstart ? kbstart[kb] : (long)kb * spk, hi = kbstart ? kbstart[kb + 1] : lo + spk;
+    if (hi > lo) {
         int b = (int)(((long)lo * G) / NS);
         while (b > 0 && (long)NS * b / G > lo) --b;
         while ((long)NS * (b + 1) / G <= lo) ++b;
@@ -668,7 +678,7 @@ __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *
         while (b + 1 < G && (long)NS * (b + 1) / G < hi) ++b;
         bl = b;
     }
-    const int ns = (bl - bf + 1) * 8 < nslot ? (bl - bf + 1) * 8 : nslot;
+    const int ns = hi <= lo ? 0 : ((bl - bf + 1) * 8 < nslot ? (bl - bf + 1) * 8 : nslot);      // a k_beta without tiles: zero
     for (int i = threadIdx.x; i < KAP * 8; i += 256) {
         const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
         if (t >= T) continue;
@@ -694,6 +704,7 @@ __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *
 #undef H2_FOLD_BODY
 #undef H2_MAXEXP
 #undef H2_MFMA
+#undef H2_RT
 
 }  // namespace
 
@@ -743,9 +754,14 @@ int launch_dft_h2(hipStream_t stream, const DftH2Args &g, const unsigned short *
         cus_of[dev] = cus;
     }
     const int tnw = g.kind == 0 ? 16 : 32;
-    const long NT = (long)(g.N / tnw) * g.batch;
-    const long NS = (NT + NWAVES - 1) / NWAVES;
+    long NT = (long)(g.N / tnw) * g.batch;
+    long NS = (NT + NWAVES - 1) / NWAVES;
     if (NS >= 2147483647L / NWAVES) return (int)hipErrorInvalidValue;
+    if (g.vlist) {             // whole super-tiles only
+        if (NT % NWAVES || g.nvalid < 1 || g.nvalid > NS) return (int)hipErrorInvalidValue;
+        NS = g.nvalid;
+        NT = NS * NWAVES;
+    }
     dim3 grid((unsigned)(NS < cus_of[dev] ? NS : cus_of[dev]));
     const uint4 *im = reinterpret_cast<const uint4 *>(img);
     static unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
@@ -766,8 +782,8 @@ int launch_dft_h2(hipStream_t stream, const DftH2Args &g, const unsigned short *
 }
 
 // workgroups of the fused adjoint pass and partial-sum slots per k_beta for `tiles_per_kb` = LP / 16 tiles per k_beta
-static void adjmix_geometry(int dev_cus, long tilesX, int hb, long &NS, int &G, int &nslot) {
-    NS = tilesX / 8 * hb;                                      // super-tiles of 8 tiles
+static void adjmix_geometry(int dev_cus, long tilesX, int hb, long nvalid, long &NS, int &G, int &nslot) {
+    NS = nvalid > 0 ? nvalid : tilesX / 8 * hb;                // super-tiles of 8 tiles (all, or the listed ones)
     long pairs = dev_cus / 16 * 8;                             // workgroup pairs (b, b + 8): the grid is a multiple of 16
     if (pairs < 8) pairs = 8;
     while (pairs > 8 && pairs > NS) pairs -= 8;
@@ -777,11 +793,11 @@ static void adjmix_geometry(int dev_cus, long tilesX, int hb, long &NS, int &G, 
     nslot = (int)(8 * ((spk + per - 1) / per + 2));
 }
 
-size_t dft_h2_adjmix_part_floats(long LP, int hb) {
+size_t dft_h2_adjmix_part_floats(long LP, int hb, long nvalid) {
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return 0;
     long NS; int G, nslot;
-    adjmix_geometry(cus, LP / 16, hb, NS, G, nslot);
+    adjmix_geometry(cus, LP / 16, hb, nvalid, NS, G, nslot);
     return (size_t)hb * nslot * 256 * 8;
 }
 
@@ -795,7 +811,9 @@ int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjM
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) return (int)hipErrorInvalidDevice;
     long NS; int G, nslot;
-    adjmix_geometry(cus, g.N / 16, g.batch, NS, G, nslot);
+    if ((am0.vlist != nullptr) != (am0.kbstart != nullptr) || (am0.vlist && (am0.nvalid < 1 || am0.nvalid > (long)(g.N / 128) * g.batch)))
+        return (int)hipErrorInvalidValue;
+    adjmix_geometry(cus, g.N / 16, g.batch, am0.vlist ? am0.nvalid : 0, NS, G, nslot);
     if (NS >= 2147483647L / 8 || g.N % 128) return (int)hipErrorInvalidValue;
     DftH2AdjMix am = am0;
     am.nslot = nslot;
@@ -805,7 +823,7 @@ int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjM
     hipLaunchKernelGGL(dft_h2_adjmix_kernel, dim3((unsigned)G), dim3(NTHREADS), ldsb, stream, g, am, reinterpret_cast<const uint4 *>(img), kA, (int)NS);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dft_h2_adjmix_reduce_kernel, dim3((unsigned)KBP), dim3(256), 0, stream, am.mpart, madj, nslot, am.T, g.Rn, (int)(PL / KBP),
-                       g.batch, KBP, PL, (int)NS, G / 2, (int)(g.N / 16 / 8), am.out_self, am.out_pair, am.Nb, am.prior_src, am.prior_mu);
+                       g.batch, KBP, PL, (int)NS, G / 2, (int)(g.N / 16 / 8), am.out_self, am.out_pair, am.Nb, am.prior_src, am.prior_mu, am.kbstart);
     return (int)hipGetLastError();
 }
 

@@ -174,6 +174,13 @@ struct surfh_plan {
     const float *spec_prior_src = nullptr;       // adjoint: + spec_prior_mu * |D|^2 * this (the quadratic prior, world = 1)
     float spec_mu = 1.f, spec_prior_mu = 0.f;
     float *adjmix_part = nullptr;                // fused adjoint tail (dft_h2_adjmix_kernel): partial sums per (k_beta, slot); null: off
+    // Support of the OTF (otf_support below): the (k_beta, chunk of 128 wavelengths) pairs -- super-tiles of the two passes that
+    // touch the OTF, index k_beta * (LP / 128) + chunk -- in which some |sotf| exceeds 2^-24 of its plane's largest magnitude.
+    // The forward's complex pass and the fused adjoint tail visit only these; otf_kbstart[kb] = first list position of kb.
+    // ycol_mix: the forward's intermediate in its own buffer, whose other tiles stay zero from plan creation on.
+    int *otf_vlist = nullptr, *otf_kbstart = nullptr;
+    int otf_nvalid = 0;
+    float *ycol_mix = nullptr;
     int h2kA[3] = {0, 0, 0};
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
     const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
@@ -897,6 +904,50 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
 // wavelengths with the template weights straight into madj [T][2][KAP][KBP] (the adjoint's tail, spectroModel.py:175-181)
 // `acols`: the source cube is zero outside the alpha range [a_lo, a_hi) (the adjoint's accumulator): the first pass
 // transforms only those columns, into ycol_adj whose other columns are zero for good
+// Support of the OTF for the two passes that multiply by it (the forward's complex pass with the fused mix, the fused adjoint
+// tail).  A PSF sampled finer than its diffraction limit has an OTF that vanishes beyond a cutoff; the reference's synthetic
+// Gaussian PSF (utils.py:40-50) falls below 2^-24 of its peak beyond 50-80 % of the k_beta range.  Products with such entries
+// are below the rounding of the plane's leading terms in fp32, so the (k_beta, 128-wavelength chunk) super-tiles in which NO
+// entry of any k_alpha reaches 2^-24 of its plane's largest magnitude are dropped from both passes -- the same set in both, so the
+// adjoint stays the transpose of the forward.  Nothing is dropped when every tile has such an entry (SURFH_OTF_SUPPORT=0: off).
+int otf_support(surfh_plan *p, const surfh_config *cfg) {
+    static const bool on = [] { const char *e = getenv("SURFH_OTF_SUPPORT"); return !(e && e[0] == '0'); }();
+    if (!on || !cfg->sotf || !p->h2 || p->T < 1 || !p->fuse_mix || p->LP % 128) return 0;
+    const int nkb = p->Nb / 2 + 1, nch = (int)(p->LP / 128);
+    std::vector<int> bmax(nch, -1);              // largest k_beta of the support over a chunk's planes (-1: none)
+    std::vector<double> km(nkb);
+    for (int l = 0; l < p->Lown; ++l) {
+        if (p->planes[l] < 0) continue;
+        std::fill(km.begin(), km.end(), 0.0);
+        double amax = 0.0;
+        const double *pl = cfg->sotf + (size_t)p->planes[l] * p->Na * nkb * 2;
+        for (int a = 0; a < p->Na; ++a)
+            for (int k = 0; k < nkb; ++k) {
+                const double re = pl[((size_t)a * nkb + k) * 2], im = pl[((size_t)a * nkb + k) * 2 + 1], m2 = re * re + im * im;
+                if (m2 > km[k]) km[k] = m2;
+            }
+        for (int k = 0; k < nkb; ++k) amax = std::max(amax, km[k]);
+        const double thr = amax * std::ldexp(1.0, -48);       // squared magnitudes
+        int b = -1;
+        for (int k = 0; k < nkb; ++k)
+            if (km[k] > thr) b = k;
+        bmax[l / 128] = std::max(bmax[l / 128], b);
+    }
+    std::vector<int> vlist, kbstart(nkb + 1, 0);
+    for (int kb = 0; kb < nkb; ++kb) {
+        kbstart[kb] = (int)vlist.size();
+        for (int j = 0; j < nch; ++j)
+            if (kb <= bmax[j]) vlist.push_back(kb * nch + j);
+    }
+    kbstart[nkb] = (int)vlist.size();
+    if (vlist.empty() || (long)vlist.size() == (long)nkb * nch) return 0;       // nothing to drop (or nothing to keep: leave the passes as they are)
+    const size_t nyc = (size_t)2 * p->NAP * p->KBP * p->LP;
+    if (dev_upload(&p->otf_vlist, vlist) || dev_upload(&p->otf_kbstart, kbstart) || dev_alloc(&p->ycol_mix, nyc)) return 1;
+    if (hipMemset(p->ycol_mix, 0, nyc * sizeof(float)) != hipSuccess) return fail("memset failed");
+    p->otf_nvalid = (int)vlist.size();
+    return 0;
+}
+
 int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = nullptr, bool acols = false) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -920,6 +971,7 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = null
     if (madj) {
         DftH2AdjMix am;
         am.hsrc = p->sotf; am.ldh = 2 * p->KBP * LP; am.sH = 2 * LP; am.tpl = p->tpl; am.T = p->T; am.LPt = (int)LP; am.mpart = p->adjmix_part;
+        if (p->otf_vlist && p->ycol_mix) { am.vlist = p->otf_vlist; am.kbstart = p->otf_kbstart; am.nvalid = p->otf_nvalid; }
         if (sub) {       // rows alpha < a_lo and alpha >= a_hi of the intermediate are zero: leading k-steps (rows k, Na - k) without a non-zero row
             int kt0 = 0;
             while (16 * kt0 + 15 < p->a_lo && p->Na - (16 * kt0 + 15) >= p->a_hi && h.KP / 16 - (kt0 + 1) >= 5) ++kt0;
@@ -953,6 +1005,10 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = 1.f; g.e_alt[3] = -1.f;
     if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
     if (mix && p->spec_in) { g.mhat = p->spec_in; g.mhat_self = 1.f; g.mhat_pair = 0.70710678118654752f; g.mix_Nb = p->Nb; }
+    // the OTF's support: tiles outside it are neither computed nor stored -- their place in ycol_mix is zero for good
+    const bool supp = mix && p->otf_vlist && p->ycol_mix && p->adjmix_part;
+    float *const yc = supp ? p->ycol_mix : p->ycol;
+    if (supp) { g.vlist = p->otf_vlist; g.nvalid = p->otf_nvalid; g.dst = yc; }
     {
         Prof pr(p, mix ? "dft_h2_cols_inv_mix" : "dft_h2_cols_inv");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img, p->h2kA[0]));
@@ -960,7 +1016,7 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     const bool sub = acols && p->a_hi > p->a_lo;
     const int a0 = sub ? p->a_lo : 0, na = sub ? p->a_hi - p->a_lo : p->Na;
     DftH2Args h;   // c2r along beta, batched over alpha: cube[b] = Gc Yr - Gs Yi, cube[N-b] = Gc Yr + Gs Yi
-    h.kind = 2; h.src = p->ycol + (long)a0 * 2 * p->KBP * LP; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
+    h.kind = 2; h.src = yc + (long)a0 * 2 * p->KBP * LP; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
     h.dst = dst + (long)a0 * LP; h.ldc = p->NAP * LP; h.sC = LP;
     h.e[0] = 1.f; h.e[1] = -1.f; h.e[2] = 1.f; h.e[3] = 1.f; h.Rn = p->Nb; h.rvalid = hb;
     h.KP = p->KPb; h.N = (int)LP; h.batch = na;
@@ -1280,6 +1336,9 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipFree(p->dft3);
     hipFree(p->h2img);
     hipFree(p->adjmix_part);
+    hipFree(p->otf_vlist);
+    hipFree(p->otf_kbstart);
+    hipFree(p->ycol_mix);
     hipFree(p->ycol_adj);
     hipFree(p->dscal);
     hipFree(p->dscratch);
@@ -1503,7 +1562,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             // (needs T <= 4 templates and 127 <= Na <= 255 output rows; SURFH_ADJ_FUSED=0: separate pass + reduction)
             const char *eaf = getenv("SURFH_ADJ_FUSED");
             if (!(eaf && eaf[0] == '0') && p->T >= 1 && p->T <= 4 && p->Na >= 127 && p->Na <= 255 && p->LP % 128 == 0) {
-                const size_t npart = dft_h2_adjmix_part_floats(p->LP, p->Nb / 2 + 1);
+                if (otf_support(p, cfg)) return bail(1);
+                const size_t npart = dft_h2_adjmix_part_floats(p->LP, p->Nb / 2 + 1, p->otf_nvalid);
                 if (npart && dev_alloc(&p->adjmix_part, npart)) return bail(1);
             }
         }
@@ -2460,6 +2520,8 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
         }
     } else if (w == "range") {         // cube columns / rows the channels' tables touch: [a_lo, a_hi) x [b_lo, b_hi)
         dims[0] = p->a_lo; dims[1] = p->a_hi; dims[2] = p->b_lo; dims[3] = p->b_hi;
+    } else if (w == "otf") {           // super-tiles (k_beta, 128 wavelengths) inside the OTF's support / all of them
+        dims[0] = p->otf_vlist ? p->otf_nvalid : (long)(p->Nb / 2 + 1) * (p->LP / 128); dims[1] = (long)(p->Nb / 2 + 1) * (p->LP / 128);
     } else if (w == "ksteps") {        // (tile, K step) pairs of the spectral-blur GEMMs: near / far of the forward, near / far of the adjoint
         for (auto &c : p->ch)
             for (int i = 0; i < 4; ++i) dims[i] += c.ksteps[i];

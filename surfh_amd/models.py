@@ -402,7 +402,7 @@ class spectroSigRLSCT(LinOp):
         dims = (C.c_int64 * 4)()
         _lib.check(self._L.surfh_debug_dims(self._plan, which.encode(), dims))
         shape = tuple(int(d) for d in dims)
-        if which in ("info", "range", "ksteps") or which.startswith("xsinfo:"):
+        if which in ("info", "range", "ksteps", "otf") or which.startswith("xsinfo:"):
             return np.array(shape)
         while len(shape) > 1 and shape[-1] == 1:
             shape = shape[:-1]

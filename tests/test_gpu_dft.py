@@ -141,3 +141,35 @@ def test_fused_adjoint_tail(shape, L, T, monkeypatch):
     e1, e0, d = rel(out["1"], ref), rel(out["0"], ref), rel(out["1"], out["0"])
     print(f"fused adjoint tail {shape} L={L} T={T}: fused {e1:.2e} separate {e0:.2e} fused vs separate {d:.2e}")
     assert e1 < TOL and e0 < TOL and d < TOL, (e1, e0, d)
+
+
+@pytest.mark.parametrize("shape,L,sig", [((251, 251), 300, (2.0, 4.5)), ((128, 200), 260, (3.0, 3.0)), ((251, 130), 140, (5.0, 2.5))])
+def test_otf_support_lists(shape, L, sig):
+    """Band-limited OTFs (clean Gaussians, widths changing along the wavelength axis): the forward's complex pass and the fused
+    adjoint tail visit only the (k_beta, 128-wavelength chunk) super-tiles in which the OTF reaches 2^-24 of its plane's peak
+    (plan.hip otf_support) -- chunks with different cutoffs, k_beta values without any tile, a cutoff that rises with the
+    wavelength.  Both directions against numpy float64, and the forward against the same plan with the lists off."""
+    import ctypes
+    from surfh_amd.mixing import Model_WCT
+    from surfh_amd.synth import ir2fr
+    rng = np.random.default_rng(L)
+    T = 3
+    hs, ws = 81, 81                      # 40 pixels = 9 sigma of the widest PSF: no truncation floor in the OTF
+    yy, xx = np.mgrid[0:hs, 0:ws]
+    s = np.linspace(sig[0], sig[1], L)
+    psfs = np.exp(-((yy - hs // 2) ** 2 + (xx - ws // 2) ** 2)[None] / (2.0 * s[:, None, None] ** 2))
+    psfs /= psfs.sum(axis=(1, 2), keepdims=True)
+    specs = rng.random((T, L)) + 0.1
+    pce = 0.5 + rng.random(L)
+    sotf = ir2fr(psfs * pce[:, None, None], shape)
+    maps = rng.random((T,) + shape)
+    cube = rng.standard_normal((L,) + shape)
+    m = Model_WCT(psfs, specs, shape, pce)
+    dims = (ctypes.c_int64 * 4)()
+    m._L.surfh_debug_dims(m._plan, b"otf", dims)
+    yf, ya = np.asarray(m.forward(maps)), np.asarray(m.adjoint(cube))
+    m.close()
+    ef, ea = rel(yf, np_forward(sotf, specs, maps)), rel(ya, np_adjoint(sotf, specs, cube))
+    print(f"otf support {shape} L={L}: {dims[0]} of {dims[1]} super-tiles, forward {ef:.2e} adjoint {ea:.2e}")
+    assert 0 < dims[0] < dims[1], list(dims)
+    assert ef < TOL and ea < TOL, (ef, ea)
