@@ -57,6 +57,10 @@ struct DftH2Args {
     // are left alone (the forward model's complex pass: the (k_beta, wavelength chunk) pairs outside the OTF's support)
     const int *vlist = nullptr;
     int nvalid = 0;
+    // optional per-tile limits, by the tile's chunk of 128 columns, chunk = (first column of the tile % tabLP) / 128:
+    // ktab[chunk] = k-steps of 16 to run (>= 2; the source rows beyond are zero or immaterial), rtab[chunk] = output rows to store
+    const int *ktab = nullptr, *rtab = nullptr;
+    int tabLP = 0;
 };
 
 // Fused tail of the adjoint: the kind-0 pass of rfft2 followed, inside the kernel, by

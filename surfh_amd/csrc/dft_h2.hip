@@ -263,7 +263,11 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
             for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
         const bool more = vt + NWAVES < vtend;
         const int next = more ? H2_RT(vt + NWAVES) : tile;
-        for (int kt = 0; kt + 1 < nk; ++kt) {
+        // per-tile limits (wave-uniform): k-steps that can be non-zero, output rows that anybody reads
+        const int chunk_ = g.tabLP ? (int)(((long)(tile % tilesX) * TNW % g.tabLP) >> 7) : 0;
+        const int nkt = g.ktab ? g.ktab[chunk_] : nk;
+        const int mtn = g.rtab ? (g.rtab[chunk_] + 31) / 32 : 4;       // row tiles of 32 that anybody reads
+        for (int kt = 0; kt + 1 < nkt; ++kt) {
             H2_MFMA(0, kt, acc1, c0h, c0l);
             H2_FOLD(kt + 1);           // raw holds k-step kt + 1 of this tile
             int p;
@@ -271,7 +275,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
             const bool need = p + e > E_LIMIT;
             en = need ? E_TARGET - p : e;
             const int d = en - e;
-            if (kt + 2 < nk) {
+            if (kt + 2 < nkt) {
                 H2_LOAD(kt + 2);
             } else if (more) {
                 H2_LSETUP(next);
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
             e = en;
         }
         // last k-step of the tile; raw holds k-step 0 of the next tile (if any)
-        H2_MFMA(0, nk - 1, acc1, c0h, c0l);
+        H2_MFMA(0, nkt - 1, acc1, c0h, c0l);
         if (more) {
             H2_FSETUP(next);
             H2_FOLD(0);
@@ -303,7 +307,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
             H2_LOAD(1);
             split8h(x0, en, c0h, c0l);
         }
-        H2_MFMA(1, nk - 1, acc2, c1h, c1l);
+        H2_MFMA(1, nkt - 1, acc2, c1h, c1l);
         if (more) split8h(x1, en, c1h, c1l);
         {
             // epilogue: descriptor of the tile's destination, rows as running scalar offsets
@@ -316,7 +320,8 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
             const unsigned lo = (unsigned)(4 * h) * ldc4 + d4, lm = (unsigned)(4 * (1 - h)) * ldc4 + d4;
             unsigned sk0 = 0u, sm0 = (unsigned)(g.Rn - 4) * ldc4;     // row / mirror row (Rn - 4 - row) byte offsets
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int mt = 0; mt < 4; ++mt) {
+                if (mt >= mtn) break;          // wave-uniform
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -334,6 +339,7 @@ __global__ __launch_bounds__(NTHREADS) void dft_h2_kernel(DftH2Args g, const uin
                     const unsigned st = ((r & 3) == 3) ? 5u * ldc4 : ldc4;
                     sk0 += st; sm0 -= st;
                 }
+            }
         }
         if (!more) break;
         e = en;
@@ -757,6 +763,7 @@ int launch_dft_h2(hipStream_t stream, const DftH2Args &g, const unsigned short *
     long NT = (long)(g.N / tnw) * g.batch;
     long NS = (NT + NWAVES - 1) / NWAVES;
     if (NS >= 2147483647L / NWAVES) return (int)hipErrorInvalidValue;
+    if ((g.ktab || g.rtab) && (g.tabLP < 128 || g.tabLP % 128)) return (int)hipErrorInvalidValue;
     if (g.vlist) {             // whole super-tiles only
         if (NT % NWAVES || g.nvalid < 1 || g.nvalid > NS) return (int)hipErrorInvalidValue;
         NS = g.nvalid;

@@ -180,6 +180,9 @@ struct surfh_plan {
     // ycol_mix: the forward's intermediate in its own buffer, whose other tiles stay zero from plan creation on.
     int *otf_vlist = nullptr, *otf_kbstart = nullptr;
     int otf_nvalid = 0;
+    // per chunk of 128 wavelengths: k-steps of the forward's complex pass (k_alpha inside the support), k-steps of its pass along
+    // beta (k_beta inside: the rest of ycol_mix is zero), rows k_beta the adjoint's first pass has to store: [3][LP / 128]
+    int *otf_tabs = nullptr;
     float *ycol_mix = nullptr;
     int h2kA[3] = {0, 0, 0};
     unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
@@ -914,17 +917,19 @@ int otf_support(surfh_plan *p, const surfh_config *cfg) {
     static const bool on = [] { const char *e = getenv("SURFH_OTF_SUPPORT"); return !(e && e[0] == '0'); }();
     if (!on || !cfg->sotf || !p->h2 || p->T < 1 || !p->fuse_mix || p->LP % 128) return 0;
     const int nkb = p->Nb / 2 + 1, nch = (int)(p->LP / 128);
-    std::vector<int> bmax(nch, -1);              // largest k_beta of the support over a chunk's planes (-1: none)
-    std::vector<double> km(nkb);
+    std::vector<int> bmax(nch, -1), amaxk(nch, -1);   // largest k_beta / folded k_alpha of the support over a chunk's planes (-1: none)
+    std::vector<double> km(nkb), kam(p->Na);
     for (int l = 0; l < p->Lown; ++l) {
         if (p->planes[l] < 0) continue;
         std::fill(km.begin(), km.end(), 0.0);
+        std::fill(kam.begin(), kam.end(), 0.0);
         double amax = 0.0;
         const double *pl = cfg->sotf + (size_t)p->planes[l] * p->Na * nkb * 2;
         for (int a = 0; a < p->Na; ++a)
             for (int k = 0; k < nkb; ++k) {
                 const double re = pl[((size_t)a * nkb + k) * 2], im = pl[((size_t)a * nkb + k) * 2 + 1], m2 = re * re + im * im;
                 if (m2 > km[k]) km[k] = m2;
+                if (m2 > kam[a]) kam[a] = m2;
             }
         for (int k = 0; k < nkb; ++k) amax = std::max(amax, km[k]);
         const double thr = amax * std::ldexp(1.0, -48);       // squared magnitudes
@@ -932,6 +937,10 @@ int otf_support(surfh_plan *p, const surfh_config *cfg) {
         for (int k = 0; k < nkb; ++k)
             if (km[k] > thr) b = k;
         bmax[l / 128] = std::max(bmax[l / 128], b);
+        int af = -1;
+        for (int a = 0; a < p->Na; ++a)
+            if (kam[a] > thr) af = std::max(af, std::min(a, p->Na - a));
+        amaxk[l / 128] = std::max(amaxk[l / 128], af);
     }
     std::vector<int> vlist, kbstart(nkb + 1, 0);
     for (int kb = 0; kb < nkb; ++kb) {
@@ -945,6 +954,14 @@ int otf_support(surfh_plan *p, const surfh_config *cfg) {
     if (dev_upload(&p->otf_vlist, vlist) || dev_upload(&p->otf_kbstart, kbstart) || dev_alloc(&p->ycol_mix, nyc)) return 1;
     if (hipMemset(p->ycol_mix, 0, nyc * sizeof(float)) != hipSuccess) return fail("memset failed");
     p->otf_nvalid = (int)vlist.size();
+    std::vector<int> tabs((size_t)3 * nch);
+    for (int j = 0; j < nch; ++j) {
+        tabs[j] = std::min(std::max((amaxk[j] + 16) / 16, 2), p->KPa / 16);
+        tabs[nch + j] = std::min(std::max((bmax[j] + 16) / 16, 2), p->KPb / 16);
+        tabs[2 * nch + j] = bmax[j] + 1;
+    }
+    static const bool ranges = [] { const char *e = getenv("SURFH_OTF_RANGES"); return !(e && e[0] == '0'); }();
+    if (ranges && dev_upload(&p->otf_tabs, tabs)) return 1;
     return 0;
 }
 
@@ -958,6 +975,8 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = null
     g.kind = 1; g.src = src + (long)a0 * LP; g.ldb = p->NAP * LP; g.Kn = p->Nb;
     g.dst = yc + 2 * (long)a0 * LP; g.ldc = 2 * p->NAP * LP; g.e[0] = 1.f; g.e[3] = -1.f; g.rvalid = hb;
     g.KP = p->KPb; g.N = (int)(na * LP);
+    // fused tail with the OTF's support: it reads no k_beta beyond the support of a wavelength chunk, so those rows are not stored
+    if (madj && p->otf_vlist && p->ycol_mix && p->otf_tabs) { g.rtab = p->otf_tabs + 2 * (LP / 128); g.tabLP = (int)LP; }
     {
         Prof pr(p, "dft_h2_rows_fwd");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img + 2 * DFT_H2_IMAGE_HALFS, p->h2kA[2]));
@@ -1009,6 +1028,7 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     const bool supp = mix && p->otf_vlist && p->ycol_mix && p->adjmix_part;
     float *const yc = supp ? p->ycol_mix : p->ycol;
     if (supp) { g.vlist = p->otf_vlist; g.nvalid = p->otf_nvalid; g.dst = yc; }
+    if (supp && p->otf_tabs) { g.ktab = p->otf_tabs; g.tabLP = (int)LP; }          // k_alpha beyond the support: not read
     {
         Prof pr(p, mix ? "dft_h2_cols_inv_mix" : "dft_h2_cols_inv");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img, p->h2kA[0]));
@@ -1020,6 +1040,7 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     h.dst = dst + (long)a0 * LP; h.ldc = p->NAP * LP; h.sC = LP;
     h.e[0] = 1.f; h.e[1] = -1.f; h.e[2] = 1.f; h.e[3] = 1.f; h.Rn = p->Nb; h.rvalid = hb;
     h.KP = p->KPb; h.N = (int)LP; h.batch = na;
+    if (supp && p->otf_tabs) { h.ktab = p->otf_tabs + LP / 128; h.tabLP = (int)LP; }   // k_beta beyond the support: zero in ycol_mix
     {
         Prof pr(p, "dft_h2_rows_inv");
         LAUNCH_OK(launch_dft_h2(p->stream, h, p->h2img + DFT_H2_IMAGE_HALFS, p->h2kA[1]));
@@ -1338,6 +1359,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipFree(p->adjmix_part);
     hipFree(p->otf_vlist);
     hipFree(p->otf_kbstart);
+    hipFree(p->otf_tabs);
     hipFree(p->ycol_mix);
     hipFree(p->ycol_adj);
     hipFree(p->dscal);
