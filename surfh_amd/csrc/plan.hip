@@ -348,6 +348,15 @@ int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>>
         grows[gi].assign(u.begin(), u.end());
         W = std::max(W, (int)grows[gi].size());
     }
+    if (const char *es = getenv("SURFH_TABLE_STATS"); es && es[0] == '1') {      // diagnostics: taps per group against taps of its members
+        size_t ut = 0, mt = 0;
+        for (size_t gi = 0; gi < NG; ++gi) {
+            ut += grows[gi].size();
+            for (size_t m = 0; m < runs[gi].second; ++m) mt += h.rows[runs[gi].first + m].size();
+        }
+        fprintf(stderr, "[surfh tables] %zu groups of <= %d rows, widest %d taps, %.2f union taps per group, %.2f taps per member row\n", NG,
+                SCATTER_G, W, (double)ut / std::max<size_t>(NG, 1), (double)mt / std::max<size_t>(h.rows.size(), 1));
+    }
     std::vector<int32_t> gcnt(NG);
     std::vector<int64_t> gcol(NG * W, 0);
     std::vector<float> gval(NG * W * SCATTER_G, 0.f);
