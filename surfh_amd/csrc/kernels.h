@@ -45,15 +45,16 @@ struct EllTable {
 // Scatter table with its rows taken SCATTER_G at a time: neighbouring cube pixels receive from almost the same operand
 // rows, so a group reads the union of its members' taps once and applies one weight per member (0 where a member does not
 // use the tap).  dst < 0 marks a missing member.
-constexpr int SCATTER_G = 4;
+constexpr int GATHER_G = 4, SCATTER_G = 8, GROUP_MAX = 8;      // rows per group: gather / scatter (measured: 4 -> 8 rows costs the
+                                                                // gather 0.34 -> 0.45 ms and gains the scatter 0.32 -> 0.28 ms per step on config 3; scatter with 16: 0.31)
 struct GroupTable {
-    int NG = 0, W = 0;                 // groups, max union taps per group
+    int NG = 0, W = 0, G = 0;          // groups, max union taps per group, rows per group (GATHER_G or SCATTER_G)
     const int32_t *cnt = nullptr;      // [NG]
     const int64_t *col = nullptr;      // [NG][W]
-    const float *val = nullptr;        // [NG][W][SCATTER_G]
-    const int64_t *dst = nullptr;      // [NG][SCATTER_G]
-    const uint32_t *rmw = nullptr;     // [NG][SCATTER_G] read-modify-write chunk masks (as EllTable::rmw)
-    const int2 *rng = nullptr;         // [NG][SCATTER_G] exact read-modify-write wavelength ranges (as EllTable::rng)
+    const float *val = nullptr;        // [NG][W][G]
+    const int64_t *dst = nullptr;      // [NG][G]
+    const uint32_t *rmw = nullptr;     // [NG][G] read-modify-write chunk masks (as EllTable::rmw)
+    const int2 *rng = nullptr;         // [NG][G] exact read-modify-write wavelength ranges (as EllTable::rng)
 };
 // float64-accumulating twin of launch_spmm_rows (every row, read-modify-write where `accumulate`)
 int launch_spmm_rows_f64acc(hipStream_t s, const EllTable &t, const float *src, float *dst, int nlam, int accumulate);

@@ -427,6 +427,7 @@ __global__ __launch_bounds__(TPB) void spmm_rows_f64acc_kernel(EllTable t, const
 }
 
 // grouped scatter: one workgroup = SCATTER_G neighbouring cube pixels x 1024 wavelengths (see GroupTable)
+template <int G>
 __global__ __launch_bounds__(TPB) void spmm_group_scatter_kernel(GroupTable t, const float *__restrict__ src, float *__restrict__ dst,
                                                                  int nlam) {
     const int per = (t.NG + 7) / 8;
@@ -435,10 +436,10 @@ __global__ __launch_bounds__(TPB) void spmm_group_scatter_kernel(GroupTable t, c
     if (gi >= t.NG || l4 >= nlam) return;
     const int n = t.cnt[gi];
     const int64_t *col = t.col + (long)gi * t.W;
-    const float *val = t.val + (long)gi * t.W * SCATTER_G;
-    float4 acc[SCATTER_G];
+    const float *val = t.val + (long)gi * t.W * G;
+    float4 acc[G];
 #pragma unroll
-    for (int g = 0; g < SCATTER_G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     int e = 0;
     constexpr int SCATTER_UNROLL = 4;      // taps in flight (2, 4, 8, 16 measured alike: 0.31-0.33 ms per step)
     for (; e + SCATTER_UNROLL <= n; e += SCATTER_UNROLL) {
@@ -448,28 +449,28 @@ __global__ __launch_bounds__(TPB) void spmm_group_scatter_kernel(GroupTable t, c
 #pragma unroll
         for (int u = 0; u < SCATTER_UNROLL; ++u)
 #pragma unroll
-            for (int g = 0; g < SCATTER_G; ++g) {
-                const float v0 = val[(e + u) * SCATTER_G + g];
+            for (int g = 0; g < G; ++g) {
+                const float v0 = val[(e + u) * G + g];
                 acc[g].x += v0 * xv[u].x; acc[g].y += v0 * xv[u].y; acc[g].z += v0 * xv[u].z; acc[g].w += v0 * xv[u].w;
             }
     }
     for (; e < n; ++e) {
         const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
 #pragma unroll
-        for (int g = 0; g < SCATTER_G; ++g) {
-            const float v0 = val[e * SCATTER_G + g];
+        for (int g = 0; g < G; ++g) {
+            const float v0 = val[e * G + g];
             acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
         }
     }
 #pragma unroll
-    for (int g = 0; g < SCATTER_G; ++g) {
-        const int64_t d = t.dst[(long)gi * SCATTER_G + g];
+    for (int g = 0; g < G; ++g) {
+        const int64_t d = t.dst[(long)gi * G + g];
         if (d < 0) continue;                               // workgroup-uniform
         float4 *p = reinterpret_cast<float4 *>(dst + d + l4);
         float4 a = acc[g];
         bool rm;
-        if (t.rng) { const int2 g2 = t.rng[(long)gi * SCATTER_G + g]; rm = l4 >= g2.x && l4 < g2.y; }
-        else rm = ((t.rmw[(long)gi * SCATTER_G + g] >> blockIdx.y) & 1u) != 0;
+        if (t.rng) { const int2 g2 = t.rng[(long)gi * G + g]; rm = l4 >= g2.x && l4 < g2.y; }
+        else rm = ((t.rmw[(long)gi * G + g] >> blockIdx.y) & 1u) != 0;
         if (rm) {
             const float4 o = *p;
             a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
@@ -542,6 +543,7 @@ __global__ __launch_bounds__(TPB) void spmm_rows_f16_kernel(EllTable t, const fl
 }
 
 // the same on a grouped table: the members' taps are read once; every member keeps its own block scale
+template <int G>
 __global__ __launch_bounds__(TPB) void spmm_group_gather_f16_kernel(GroupTable t, const float *__restrict__ src,
                                                                     unsigned short *__restrict__ dst16, long plane, int nlam,
                                                                     float *__restrict__ bscale, int NP, long K, int LinP, int nchunk) {
@@ -550,13 +552,13 @@ __global__ __launch_bounds__(TPB) void spmm_group_gather_f16_kernel(GroupTable t
     const int gi = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
     const int l4 = (blockIdx.y * TPB + threadIdx.x) * 4;
     if (gi >= t.NG) return;                               // workgroup-uniform
-    float4 acc[SCATTER_G];
+    float4 acc[G];
 #pragma unroll
-    for (int g = 0; g < SCATTER_G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int g = 0; g < G; ++g) acc[g] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (l4 < nlam) {
         const int n = t.cnt[gi];
         const int64_t *col = t.col + (long)gi * t.W;
-        const float *val = t.val + (long)gi * t.W * SCATTER_G;
+        const float *val = t.val + (long)gi * t.W * G;
         int e = 0;
         // eight taps requested before the first is used: with two the kernel waited on memory latency (0.45 -> 0.34 ms per
         // step on config 3; 4: 0.36, 12 / 16 / 24: 0.36 / 0.38 / 0.36; fewer resident workgroups only cost time)
@@ -568,31 +570,31 @@ __global__ __launch_bounds__(TPB) void spmm_group_gather_f16_kernel(GroupTable t
 #pragma unroll
             for (int u = 0; u < GATHER_UNROLL; ++u)
 #pragma unroll
-                for (int g = 0; g < SCATTER_G; ++g) {
-                    const float v0 = val[(e + u) * SCATTER_G + g];
+                for (int g = 0; g < G; ++g) {
+                    const float v0 = val[(e + u) * G + g];
                     acc[g].x += v0 * xv[u].x; acc[g].y += v0 * xv[u].y; acc[g].z += v0 * xv[u].z; acc[g].w += v0 * xv[u].w;
                 }
         }
         for (; e < n; ++e) {
             const float4 x0 = *reinterpret_cast<const float4 *>(src + col[e] + l4);
 #pragma unroll
-            for (int g = 0; g < SCATTER_G; ++g) {
-                const float v0 = val[e * SCATTER_G + g];
+            for (int g = 0; g < G; ++g) {
+                const float v0 = val[e * G + g];
                 acc[g].x += v0 * x0.x; acc[g].y += v0 * x0.y; acc[g].z += v0 * x0.z; acc[g].w += v0 * x0.w;
             }
         }
     }
-    __shared__ float sm[SCATTER_G][TPB / 64];
+    __shared__ float sm[G][TPB / 64];
 #pragma unroll
-    for (int g = 0; g < SCATTER_G; ++g) {
+    for (int g = 0; g < G; ++g) {
         float m = fmaxf(fmaxf(fabsf(acc[g].x), fabsf(acc[g].y)), fmaxf(fabsf(acc[g].z), fabsf(acc[g].w)));
         for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
         if ((threadIdx.x & 63) == 0) sm[g][threadIdx.x >> 6] = m;
     }
     __syncthreads();
 #pragma unroll
-    for (int g = 0; g < SCATTER_G; ++g) {
-        const int64_t off = t.dst[(long)gi * SCATTER_G + g];
+    for (int g = 0; g < G; ++g) {
+        const int64_t off = t.dst[(long)gi * G + g];
         if (off < 0) continue;                             // workgroup-uniform
         const float scale = f16x2_block_scale(fmaxf(fmaxf(sm[g][0], sm[g][1]), fmaxf(sm[g][2], sm[g][3]))), inv = 1.f / scale;
         if (threadIdx.x == 0) bscale[((off % K) / LinP * nchunk + blockIdx.y) * (long)NP + off / K] = scale;
@@ -1154,7 +1156,9 @@ int launch_spmm_group_scatter(hipStream_t s, const GroupTable &t, const float *s
     if (t.NG == 0 || nlam <= 0) return 0;
     if (nlam % 4 || (nlam / 4 + TPB - 1) / TPB > 32) return (int)hipErrorInvalidValue;
     dim3 grid((t.NG + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(spmm_group_scatter_kernel, grid, dim3(TPB), 0, s, t, src, dst, nlam);
+    if (t.G == 4) hipLaunchKernelGGL(spmm_group_scatter_kernel<4>, grid, dim3(TPB), 0, s, t, src, dst, nlam);
+    else if (t.G == 8) hipLaunchKernelGGL(spmm_group_scatter_kernel<8>, grid, dim3(TPB), 0, s, t, src, dst, nlam);
+    else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 
@@ -1172,8 +1176,11 @@ int launch_spmm_group_gather_f16(hipStream_t s, const GroupTable &t, const float
     if (t.NG == 0 || nlam <= 0) return 0;
     if (nlam % 4 || plane % 4 || K % LinP || LinP % 32 || !bscale) return (int)hipErrorInvalidValue;
     dim3 grid((t.NG + 7) / 8 * 8, (nlam / 4 + TPB - 1) / TPB);
-    hipLaunchKernelGGL(spmm_group_gather_f16_kernel, grid, dim3(TPB), 0, s, t, src, dst16, plane, nlam, bscale, NP, K, LinP,
-                       (LinP + 1023) / 1024);
+    if (t.G == 4)
+        hipLaunchKernelGGL(spmm_group_gather_f16_kernel<4>, grid, dim3(TPB), 0, s, t, src, dst16, plane, nlam, bscale, NP, K, LinP, (LinP + 1023) / 1024);
+    else if (t.G == 8)
+        hipLaunchKernelGGL(spmm_group_gather_f16_kernel<8>, grid, dim3(TPB), 0, s, t, src, dst16, plane, nlam, bscale, NP, K, LinP, (LinP + 1023) / 1024);
+    else return (int)hipErrorInvalidValue;
     return (int)hipGetLastError();
 }
 

@@ -325,25 +325,25 @@ void free_ell(DevEll *d) {
 
 // rows [r, r + n) of h taken as one group: union of their taps with one weight per member
 int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>> &runs, const std::vector<uint32_t> *mask, DevEll *d,
-                  const std::vector<int2> *ranges = nullptr) {
+                  const int G, const std::vector<int2> *ranges = nullptr) {
     const size_t NG = runs.size();
-    std::vector<std::vector<std::pair<int64_t, std::array<float, SCATTER_G>>>> grows(NG);
-    std::vector<int64_t> gdst(NG * SCATTER_G, -1);
-    std::vector<uint32_t> grmw(NG * SCATTER_G, 0u);
-    std::vector<int2> grng(ranges ? NG * SCATTER_G : 0, make_int2(0, 0));
+    std::vector<std::vector<std::pair<int64_t, std::array<float, GROUP_MAX>>>> grows(NG);
+    std::vector<int64_t> gdst(NG * G, -1);
+    std::vector<uint32_t> grmw(NG * G, 0u);
+    std::vector<int2> grng(ranges ? NG * G : 0, make_int2(0, 0));
     int W = 1;
     for (size_t gi = 0; gi < NG; ++gi) {
         const size_t r = runs[gi].first, n = runs[gi].second;
-        std::map<int64_t, std::array<float, SCATTER_G>> u;
+        std::map<int64_t, std::array<float, GROUP_MAX>> u;
         for (size_t m = 0; m < n; ++m) {
             for (auto &e : h.rows[r + m]) {
                 auto it = u.find(e.first);
-                if (it == u.end()) it = u.emplace(e.first, std::array<float, SCATTER_G>{}).first;
+                if (it == u.end()) it = u.emplace(e.first, std::array<float, GROUP_MAX>{}).first;
                 it->second[m] += e.second;
             }
-            gdst[gi * SCATTER_G + m] = h.dst[r + m];
-            if (mask) grmw[gi * SCATTER_G + m] = (*mask)[r + m];
-            if (ranges) grng[gi * SCATTER_G + m] = (*ranges)[r + m];
+            gdst[gi * G + m] = h.dst[r + m];
+            if (mask) grmw[gi * G + m] = (*mask)[r + m];
+            if (ranges) grng[gi * G + m] = (*ranges)[r + m];
         }
         grows[gi].assign(u.begin(), u.end());
         W = std::max(W, (int)grows[gi].size());
@@ -355,22 +355,22 @@ int upload_groups(const HostEll &h, const std::vector<std::pair<size_t, size_t>>
             for (size_t m = 0; m < runs[gi].second; ++m) mt += h.rows[runs[gi].first + m].size();
         }
         fprintf(stderr, "[surfh tables] %zu groups of <= %d rows, widest %d taps, %.2f union taps per group, %.2f taps per member row\n", NG,
-                SCATTER_G, W, (double)ut / std::max<size_t>(NG, 1), (double)mt / std::max<size_t>(h.rows.size(), 1));
+                G, W, (double)ut / std::max<size_t>(NG, 1), (double)mt / std::max<size_t>(h.rows.size(), 1));
     }
     std::vector<int32_t> gcnt(NG);
     std::vector<int64_t> gcol(NG * W, 0);
-    std::vector<float> gval(NG * W * SCATTER_G, 0.f);
+    std::vector<float> gval(NG * W * G, 0.f);
     for (size_t gi = 0; gi < NG; ++gi) {
         gcnt[gi] = (int32_t)grows[gi].size();
         for (size_t e = 0; e < grows[gi].size(); ++e) {
             gcol[gi * W + e] = grows[gi][e].first;
-            for (int m = 0; m < SCATTER_G; ++m) gval[(gi * W + e) * SCATTER_G + m] = grows[gi][e].second[m];
+            for (int m = 0; m < G; ++m) gval[(gi * W + e) * G + m] = grows[gi][e].second[m];
         }
     }
     if (dev_upload(&d->g_cnt, gcnt) || dev_upload(&d->g_col, gcol) || dev_upload(&d->g_val, gval) || dev_upload(&d->g_dst, gdst) ||
         dev_upload(&d->g_rmw, grmw))
         return 1;
-    d->g.NG = (int)NG; d->g.W = W; d->g.cnt = d->g_cnt; d->g.col = d->g_col; d->g.val = d->g_val; d->g.dst = d->g_dst; d->g.rmw = d->g_rmw;
+    d->g.NG = (int)NG; d->g.W = W; d->g.G = G; d->g.cnt = d->g_cnt; d->g.col = d->g_col; d->g.val = d->g_val; d->g.dst = d->g_dst; d->g.rmw = d->g_rmw;
     if (ranges) {
         if (dev_upload(&d->g_rng, grng)) return 1;
         d->g.rng = d->g_rng;
@@ -497,10 +497,10 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
         f = std::move(g);
     }
     if (upload_ell(f, &c->fwd)) return 1;
-    if (p->gather_grouped && p->gather_sorted && !c->bsum) {      // SCATTER_G rows neighbouring in cube-location order per workgroup
+    if (p->gather_grouped && p->gather_sorted && !c->bsum) {      // GATHER_G rows neighbouring in cube-location order per workgroup
         std::vector<std::pair<size_t, size_t>> runs;
-        for (size_t r = 0; r < f.rows.size(); r += SCATTER_G) runs.push_back({r, std::min<size_t>(SCATTER_G, f.rows.size() - r)});
-        if (upload_groups(f, runs, nullptr, &c->fwd)) return 1;
+        for (size_t r = 0; r < f.rows.size(); r += GATHER_G) runs.push_back({r, std::min<size_t>(GATHER_G, f.rows.size() - r)});
+        if (upload_groups(f, runs, nullptr, &c->fwd, GATHER_G)) return 1;
     }
 
     // ---- exact transpose: rows = touched cube pixels ------------------------------------------
@@ -1757,7 +1757,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                     runs.push_back({r, n});
                     r += n;
                 }
-                if (upload_groups(h, runs, &mask, &c.adjT, &ranges)) return bail(1);
+                if (upload_groups(h, runs, &mask, &c.adjT, SCATTER_G, &ranges)) return bail(1);
             }
             c.adjT_host = HostEll();
             if (dev_upload(&c.adjT.rmw, mask) || dev_upload(&c.adjT.rng, ranges)) return bail(1);
