@@ -178,14 +178,22 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
     unsigned char *sctab = reinterpret_cast<unsigned char *>(lds + 2 * STAGE);     // [segment][256 rows] exponent fields of A's block scales
     int *klds = reinterpret_cast<int *>(sctab + CC2_MAXSEG * BM);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tilesM = (g.M + BM - 1) / BM, tilesN = (g.N + BN - 1) / BN, tiles = tilesM * tilesN;
+    // tile columns: 256 consecutive rows of B, or (permP > 0) Q = 256 / permP consecutive rows of each of permP neighbouring columns
+    const int Q = g.permP ? BN / g.permP : BN, tilesL = g.permP ? g.permLin / Q : 0, ncol = g.permP ? g.N / g.permLin : 0;
+    const int tilesM = (g.M + BM - 1) / BM, tilesN = g.permP ? (ncol + g.permP - 1) / g.permP * tilesL : (g.N + BN - 1) / BN, tiles = tilesM * tilesN;
+    // row of B (= column of C) of tile-local column v of tile column tn_; -1: none (a column group beyond the last)
+    auto bcol = [&](int tn_, int v) __attribute__((always_inline)) {
+        if (!g.permP) { const int n = tn_ * BN + v; return n < g.N ? n : -1; }
+        const int c = (tn_ / tilesL) * g.permP + v / Q;
+        return c < ncol ? c * g.permLin + (tn_ % tilesL) * Q + v % Q : -1;
+    };
     const long total = (long)tiles * g.splitK * g.batch, per = (total + 7) / 8;
     const long v = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
     if ((long)(blockIdx.x >> 3) >= per || v >= total) return;
     const int t = (int)(v % tiles), z = (int)(v / tiles);
     const int tm = t % tilesM, tn = t / tilesM;
     const int b = z / g.splitK, sk = z % g.splitK;
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * BM;
     const float *bs = g.bscale;
 
     // this slab's K steps: near ones first, then the far ones, each in ascending order
@@ -228,8 +236,8 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
             int m = m0 + (wave + 8 * i) * 16 + (lane >> 2);
             m = m < g.M ? m : g.M - 1;
             offA[i] = (unsigned)(((long)m * g.lda + 8 * chunk) * 2);
-            int n = n0 + (wave + 8 * i) * 16 + (lane >> 2);
-            n = n < g.N ? n : g.N - 1;
+            int n = bcol(tn, (wave + 8 * i) * 16 + (lane >> 2));
+            n = n >= 0 ? n : g.N - 1;
             offB[i] = (unsigned)(((long)n * g.ldb + 8 * chunk) * 2);
         }
     }
@@ -383,7 +391,13 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
 #undef CC_DMA
 #undef CC_RD
     {
-        char *Cb = reinterpret_cast<char *>(g.C + (long)b * g.sC + (long)sk * g.sCsplit + (long)m0 * g.ldc + n0);
+        char *Cb = reinterpret_cast<char *>(g.C + (long)b * g.sC + (long)sk * g.sCsplit + (long)m0 * g.ldc);
+        int cj[8];                                 // column of C of the lane's element of column block j (-1: none); blocks of 16 stay whole
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c0 = bcol(tn, wn * 128 + j * 16);
+            cj[j] = c0 >= 0 ? c0 + l15 : -1;
+        }
         const unsigned ldc4 = (unsigned)(g.ldc * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -399,10 +413,10 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
             for (int r = 0; r < 4; ++r) {
                 const int row = m0 + srow + i * 16 + r;
                 const float sc = rsc[r] * g.sB16;
-                const unsigned o_ = (unsigned)(srow + i * 16 + r) * ldc4 + (unsigned)(wn * 128 + l15) * 4u;
+                const unsigned o_ = (unsigned)(srow + i * 16 + r) * ldc4;
 #pragma unroll
                 for (int j = 0; j < 8; ++j)
-                    if (row < g.M && n0 + wn * 128 + j * 16 + l15 < g.N) *reinterpret_cast<float *>(Cb + (o_ + 64u * j)) = acc[i][j][r] * sc;
+                    if (row < g.M && cj[j] >= 0 && cj[j] < g.N) *reinterpret_cast<float *>(Cb + (o_ + (unsigned)cj[j] * 4u)) = acc[i][j][r] * sc;
             }
         }
     }
@@ -472,7 +486,13 @@ int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g) {
                 if (seg_of(sk * Kper + Kper - 1) - seg_of(sk * Kper) + 1 > CC2_MAXSEG) return (int)hipErrorInvalidValue;
         }
     }
-    const long total = (long)((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN) * g.batch * g.splitK;
+    long tilesN = (g.N + BN - 1) / BN;
+    if (g.permP) {
+        if ((g.permP != 1 && g.permP != 2 && g.permP != 4 && g.permP != 8) || g.permLin < 1 || g.permLin % (BN / g.permP) || g.N % g.permLin)
+            return (int)hipErrorInvalidValue;
+        tilesN = (long)((g.N / g.permLin + g.permP - 1) / g.permP) * (g.permLin / (BN / g.permP));
+    }
+    const long total = (long)((g.M + BM - 1) / BM) * tilesN * g.batch * g.splitK;
     dim3 grid((unsigned)(8 * ((total + 7) / 8)));
     static unsigned long long attr_done = 0;
     if (int e = ensure_dynamic_lds(gemm_nt_f16x2_cc_kernel, LDS3_BYTES, attr_done)) return e;

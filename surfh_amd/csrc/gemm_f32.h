@@ -39,6 +39,10 @@ struct GemmArgs {
     // bscale).  Near steps keep three products per element, far steps only the leading one (build_klist, plan.hip)
     const int *klist = nullptr;
     int klistStride = 0;
+    // optional tile shape of the two-piece fp16 kernel along N for a B whose rows come in columns of permLin consecutive rows (N = ncol * permLin): a tile then takes 256 / permP consecutive rows of each of permP
+    // neighbouring columns instead of 256 consecutive rows (the adjoint spectral-blur GEMM: rows of the same wavelengths share
+    // their near K steps).  permP in {1, 2, 4, 8}, permLin % (256 / permP) == 0; 0: plain tiles
+    int permP = 0, permLin = 0;
 };
 
 // returns hipError_t as int; name is used by the profiler

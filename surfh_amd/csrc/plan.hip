@@ -105,6 +105,7 @@ struct Channel {
     // all three products and the steps kept as h*h only; ksteps = (near, far) of the forward, (near, far) of the adjoint
     int *klF = nullptr, *klA = nullptr;
     int klFs = 0, klAs = 0;
+    int permA = 0;                      // adjoint GEMM: a tile takes 256 / permA wavelengths of each of permA neighbouring beta columns (0: 256 consecutive rows)
     long ksteps[4] = {0, 0, 0, 0};
     unsigned *amax = nullptr;                       // [2][NP] max |row| of the data operands: Xs (forward), ymat (adjoint)
     unsigned *pmax = nullptr;                       // per-wave maxima of the kernel that wrote the operand (reduced into amax)
@@ -600,8 +601,15 @@ int build_channel(surfh_plan *p, const surfh_channel_desc &d, Channel *c) {
 // its diagonal: about two thirds of the steps of a tile qualify.  Record per tile: [n_near, n_far, near..., far...], entry =
 // step | segment << 16 (gemm_f32.h).  Fewer than 8 far steps are not worth the second pass: all near.
 int build_klist(const float *B, int N, int K, long ldb, int segLinP, int segChunks, double tol1, double tol2, std::vector<int> *out,
-                int *stride, long *n_near, long *n_far) {
-    const int nb = K / 32, tilesN = (N + 255) / 256;
+                int *stride, long *n_near, long *n_far, int permP = 0, int permLin = 0) {
+    // tile columns as in the kernel: 256 consecutive rows, or 256 / permP rows of each of permP neighbouring columns of permLin rows
+    const int Q = permP ? 256 / permP : 256, tilesL = permP ? permLin / Q : 0, ncol = permP ? N / permLin : 0;
+    const int nb = K / 32, tilesN = permP ? (ncol + permP - 1) / permP * tilesL : (N + 255) / 256;
+    auto brow = [&](int tn, int v) {
+        if (!permP) { const int n = tn * 256 + v; return n < N ? n : -1; }
+        const int c = (tn / tilesL) * permP + v / Q;
+        return c < ncol ? c * permLin + (tn % tilesL) * Q + v % Q : -1;
+    };
     *stride = 2 + nb;
     out->assign((size_t)tilesN * *stride, 0);
     *n_near = *n_far = 0;
@@ -609,9 +617,15 @@ int build_klist(const float *B, int N, int K, long ldb, int segLinP, int segChun
     std::vector<int> order(nb);
     std::vector<char> far(nb);
     for (int tn = 0; tn < tilesN; ++tn) {
-        const int r0 = tn * 256, nr = std::min(256, N - r0);
+        const int nr = 256;
         for (int r = 0; r < nr; ++r) {
-            const float *row = B + (long)(r0 + r) * ldb;
+            const int br = brow(tn, r);
+            if (br < 0) {          // no such row: nothing to bound
+                for (int b = 0; b < nb; ++b) l1[(size_t)r * nb + b] = l2[(size_t)r * nb + b] = 0.0;
+                L1[r] = L2[r] = 0.0;
+                continue;
+            }
+            const float *row = B + (long)br * ldb;
             double s1 = 0.0, s2 = 0.0;
             for (int b = 0; b < nb; ++b) {
                 double a1 = 0.0, a2 = 0.0;
@@ -1268,6 +1282,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
                 if (!have16) LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
                 g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
                 g.klist = c.klA; g.klistStride = c.klAs;
+                if (c.klA && c.permA) { g.permP = c.permA; g.permLin = c.LinP; }
                 LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
         }
@@ -1678,8 +1693,15 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                 build_klist(hw.data(), c.LdetP, c.K, c.K, c.LinP, segChunks, 1.0 / 256, 1.0 / 1024, &kl, &c.klFs, &c.ksteps[0], &c.ksteps[1]);
                 if (c.ksteps[1] > 0 && dev_upload(&c.klF, kl)) return bail(1);
                 if (hipMemcpy(hw.data(), c.Wt, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return bail(fail("copy failed"));
-                build_klist(hw.data(), c.K, KA, c.LdetP, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &c.klAs, &c.ksteps[2], &c.ksteps[3]);
-                if (c.ksteps[3] > 0 && dev_upload(&c.klA, kl)) return bail(1);
+                // the adjoint's constant operand has one row per (beta column, wavelength): a tile of 64 wavelengths of four
+                // neighbouring columns sees the response's diagonal in 2-3 of its K steps, 256 wavelengths of one column in 9
+                static const bool perm = [] { const char *e = getenv("SURFH_WBLUR_PERM"); return !(e && e[0] == '0'); }();
+                const int pP = perm && c.LinP % 64 == 0 && c.nbs >= 4 ? 4 : 0;
+                build_klist(hw.data(), c.K, KA, c.LdetP, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &c.klAs, &c.ksteps[2], &c.ksteps[3], pP, c.LinP);
+                if (c.ksteps[3] > 0) {
+                    if (dev_upload(&c.klA, kl)) return bail(1);
+                    c.permA = pP;
+                }
             }
         }
         if (dev_alloc(&c.Cpart, (size_t)c.splitK * c.LdetP * c.NP)) return bail(1);
@@ -2637,7 +2659,12 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
         g_selftest_ksteps[0] = g_selftest_ksteps[1] = 0;
         if (mode[0] == '2') {      // with K-step lists, classes and tolerances as at plan creation
             std::vector<int> kl;
-            build_klist(bt.data(), N, K, K, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &g.klistStride, &g_selftest_ksteps[0], &g_selftest_ksteps[1]);
+            // SURFH_SELFTEST_PERM=<rows per column of B>: tiles of 64 rows of four neighbouring columns, as the adjoint spectral-blur GEMM
+            const char *ep = getenv("SURFH_SELFTEST_PERM");
+            const int lin = ep ? atoi(ep) : 0;
+            if (lin > 0) { g.permP = 4; g.permLin = lin; }
+            build_klist(bt.data(), N, K, K, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &g.klistStride, &g_selftest_ksteps[0], &g_selftest_ksteps[1], g.permP,
+                        g.permLin);
             if (dev_upload(&dkl, kl)) return 1;
             g.klist = dkl;
         }

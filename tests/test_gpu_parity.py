@@ -123,6 +123,27 @@ def test_gemm_two_piece_fp16_k_step_classes():
                 e = rel(Cg, A.astype(np.float64) @ B.astype(np.float64))
                 note("gemm_f16x2_klist", M=M, N=N, K=K, sk=sk, data=name, near=int(ks[0]), far=int(ks[1]), err=e)
                 assert ks[1] > ks[0] and e < 1e-6, (M, N, K, sk, name, list(ks), e)
+        # the adjoint's shape: the constant operand has one row per (beta column, wavelength), K runs over the detector axis; a tile
+        # is 64 wavelengths of four neighbouring columns (GemmArgs::permP), incl. a last group with missing columns (5 = 4 + 1)
+        for (M, Ldet, Lin, ncol) in [(256, 1024, 1152, 4), (128, 640, 768, 5)]:
+            lo, li = np.arange(Ldet)[:, None], np.arange(Lin)[None, :]
+            cols = []
+            for c in range(ncol):
+                w = np.sinc((li - (lo * (Lin / Ldet) + 3.0 * c)) / 2.3) ** 2
+                cols.append(w / w.sum(axis=1, keepdims=True))
+            Wt = np.ascontiguousarray(np.concatenate(cols, axis=1)).astype(np.float32)      # [K = Ldet][N = ncol * Lin], as the hook wants B
+            N = ncol * Lin
+            A = (rng.random((M, Ldet)) * 50 + 1).astype(np.float32)
+            Cg = np.empty((M, N), dtype=np.float32)
+            os.environ["SURFH_SELFTEST_PERM"] = str(Lin)
+            try:
+                _lib.check(L.surfh_gemm_selftest(0, M, N, Ldet, 1, _lib.fptr(A), _lib.fptr(Wt), _lib.fptr(Cg)))
+            finally:
+                os.environ.pop("SURFH_SELFTEST_PERM")
+            L.surfh_gemm_selftest_ksteps(ks)
+            e = rel(Cg, A.astype(np.float64) @ Wt.astype(np.float64))
+            note("gemm_f16x2_klist_perm", M=M, N=N, K=Ldet, near=int(ks[0]), far=int(ks[1]), err=e)
+            assert ks[1] > ks[0] and e < 1e-6, (M, N, Ldet, list(ks), e)
         M, N, K = 256, 384, 1056
         A = rng.standard_normal((M, K)).astype(np.float32)
         B = rng.standard_normal((K, N)).astype(np.float32)
