@@ -319,7 +319,10 @@ def main():
                                               "frac": ach / HBM_PEAK_GBS, "kernel": "+".join(sorted(k for k, _ in dft)),
                                               "launches_per_step": n_l / max(n_all, 1), "ms_per_step": t_step * 1e3,
                                               "note": "whole stage: algorithmic bytes of a step's two 2-D transforms (OTF read once and "
-                                                      "cube written / read once per direction) over the time of every kernel of the stage"}
+                                                      "cube written / read once per direction) over the time of every kernel of the stage; "
+                                                      "the passes visit only the spectrum tiles inside the OTF's support (otf_tiles_in_support_of), "
+                                                      "so they move fewer bytes than the algorithmic count",
+                                              "otf_tiles_in_support_of": [int(v) for v in m.debug_buffer("otf")[:2]]}
         # the matrix-core half of the path, whichever group dominates: R / R^T against the fp32-MFMA peak
         gm = [(k, v) for k, v in (groups if dom_prefix == "gemm_wblur" else groups_all).items() if k.startswith("gemm_nt")]
         if gm:

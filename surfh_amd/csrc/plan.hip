@@ -1685,19 +1685,20 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
                 return bail(fail("operand split failed"));
             static const bool far_steps = [] { const char *e = getenv("SURFH_WBLUR_FAR"); return !(e && e[0] == '0'); }();
+            static const double far_tol2 = [] { const char *e = getenv("SURFH_WBLUR_FAR_TOL2"); return std::ldexp(1.0, -(e ? atoi(e) : 10)); }();
             const int segChunks = (c.LinP + 1023) / 1024, KA = (c.Ldet + 31) / 32 * 32;
             if (far_steps && c.K / 32 <= 1024 && c.nbs * segChunks <= 64 && KA / 32 <= 1024) {
                 std::vector<float> hw((size_t)nw);
                 std::vector<int> kl;
                 if (hipMemcpy(hw.data(), c.W, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return bail(fail("copy failed"));
-                build_klist(hw.data(), c.LdetP, c.K, c.K, c.LinP, segChunks, 1.0 / 256, 1.0 / 1024, &kl, &c.klFs, &c.ksteps[0], &c.ksteps[1]);
+                build_klist(hw.data(), c.LdetP, c.K, c.K, c.LinP, segChunks, 1.0 / 256, far_tol2, &kl, &c.klFs, &c.ksteps[0], &c.ksteps[1]);
                 if (c.ksteps[1] > 0 && dev_upload(&c.klF, kl)) return bail(1);
                 if (hipMemcpy(hw.data(), c.Wt, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return bail(fail("copy failed"));
                 // the adjoint's constant operand has one row per (beta column, wavelength): a tile of 64 wavelengths of four
                 // neighbouring columns sees the response's diagonal in 2-3 of its K steps, 256 wavelengths of one column in 9
                 static const bool perm = [] { const char *e = getenv("SURFH_WBLUR_PERM"); return !(e && e[0] == '0'); }();
                 const int pP = perm && c.LinP % 64 == 0 && c.nbs >= 4 ? 4 : 0;
-                build_klist(hw.data(), c.K, KA, c.LdetP, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &c.klAs, &c.ksteps[2], &c.ksteps[3], pP, c.LinP);
+                build_klist(hw.data(), c.K, KA, c.LdetP, 0, 0, 1.0 / 256, far_tol2, &kl, &c.klAs, &c.ksteps[2], &c.ksteps[3], pP, c.LinP);
                 if (c.ksteps[3] > 0) {
                     if (dev_upload(&c.klA, kl)) return bail(1);
                     c.permA = pP;
