@@ -937,7 +937,7 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
 // entry of any k_alpha reaches 2^-24 of its plane's largest magnitude are dropped from both passes -- the same set in both, so the
 // adjoint stays the transpose of the forward.  Nothing is dropped when every tile has such an entry (SURFH_OTF_SUPPORT=0: off).
 int otf_support(surfh_plan *p, const surfh_config *cfg) {
-    static const bool on = [] { const char *e = getenv("SURFH_OTF_SUPPORT"); return !(e && e[0] == '0'); }();
+    const bool on = [] { const char *e = getenv("SURFH_OTF_SUPPORT"); return !(e && e[0] == '0'); }();      // read at plan creation
     if (!on || !cfg->sotf || !p->h2 || p->T < 1 || !p->fuse_mix || p->LP % 128) return 0;
     const int nkb = p->Nb / 2 + 1, nch = (int)(p->LP / 128);
     std::vector<int> bmax(nch, -1), amaxk(nch, -1);   // largest k_beta / folded k_alpha of the support over a chunk's planes (-1: none)
@@ -983,7 +983,7 @@ int otf_support(surfh_plan *p, const surfh_config *cfg) {
         tabs[nch + j] = std::min(std::max((bmax[j] + 16) / 16, 2), p->KPb / 16);
         tabs[2 * nch + j] = bmax[j] + 1;
     }
-    static const bool ranges = [] { const char *e = getenv("SURFH_OTF_RANGES"); return !(e && e[0] == '0'); }();
+    const bool ranges = [] { const char *e = getenv("SURFH_OTF_RANGES"); return !(e && e[0] == '0'); }();
     if (ranges && dev_upload(&p->otf_tabs, tabs)) return 1;
     return 0;
 }
@@ -1684,8 +1684,8 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             if (dev_upload(&c.bscale, ones)) return bail(1);
             if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
                 return bail(fail("operand split failed"));
-            static const bool far_steps = [] { const char *e = getenv("SURFH_WBLUR_FAR"); return !(e && e[0] == '0'); }();
-            static const double far_tol2 = [] { const char *e = getenv("SURFH_WBLUR_FAR_TOL2"); return std::ldexp(1.0, -(e ? atoi(e) : 10)); }();
+            const bool far_steps = [] { const char *e = getenv("SURFH_WBLUR_FAR"); return !(e && e[0] == '0'); }();      // read at plan creation
+            const double far_tol2 = [] { const char *e = getenv("SURFH_WBLUR_FAR_TOL2"); return std::ldexp(1.0, -(e ? atoi(e) : 10)); }();
             const int segChunks = (c.LinP + 1023) / 1024, KA = (c.Ldet + 31) / 32 * 32;
             if (far_steps && c.K / 32 <= 1024 && c.nbs * segChunks <= 64 && KA / 32 <= 1024) {
                 std::vector<float> hw((size_t)nw);
@@ -1696,7 +1696,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                 if (hipMemcpy(hw.data(), c.Wt, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return bail(fail("copy failed"));
                 // the adjoint's constant operand has one row per (beta column, wavelength): a tile of 64 wavelengths of four
                 // neighbouring columns sees the response's diagonal in 2-3 of its K steps, 256 wavelengths of one column in 9
-                static const bool perm = [] { const char *e = getenv("SURFH_WBLUR_PERM"); return !(e && e[0] == '0'); }();
+                const bool perm = [] { const char *e = getenv("SURFH_WBLUR_PERM"); return !(e && e[0] == '0'); }();
                 const int pP = perm && c.LinP % 64 == 0 && c.nbs >= 4 ? 4 : 0;
                 build_klist(hw.data(), c.K, KA, c.LdetP, 0, 0, 1.0 / 256, far_tol2, &kl, &c.klAs, &c.ksteps[2], &c.ksteps[3], pP, c.LinP);
                 if (c.ksteps[3] > 0) {
