@@ -170,7 +170,7 @@ __device__ __forceinline__ void cc16_unit(f32x4v (&acc)[4][8], f16x8 (&A)[4][2],
 // the host bounded (plan.hip: build_klist; far steps of a row sum to < 2^-8 of its l1 norm and < 2^-10 of its l2 norm).  A far
 // step issues a third of the MFMAs and moves half the operand bytes: 0.44 of the time of a near one (tools/exp/cc_main.hip).
 // Without lists every step of the slab is near, in ascending order.  List entry = K step | segment of A's block scales << 16.
-constexpr int CC2_MAXLIST = 1024;                                     // K steps of one slab (launcher checks)
+constexpr int CC2_MAXLIST = 2048;                                     // K steps of one slab (launcher checks)
 constexpr size_t LDS3_BYTES = LDS2_BYTES + (size_t)CC2_MAXLIST * sizeof(int);
 
 __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {

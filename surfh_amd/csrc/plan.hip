@@ -1687,7 +1687,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             const bool far_steps = [] { const char *e = getenv("SURFH_WBLUR_FAR"); return !(e && e[0] == '0'); }();      // read at plan creation
             const double far_tol2 = [] { const char *e = getenv("SURFH_WBLUR_FAR_TOL2"); return std::ldexp(1.0, -(e ? atoi(e) : 10)); }();
             const int segChunks = (c.LinP + 1023) / 1024, KA = (c.Ldet + 31) / 32 * 32;
-            if (far_steps && c.K / 32 <= 1024 && c.nbs * segChunks <= 64 && KA / 32 <= 1024) {
+            if (far_steps && c.K / 32 <= 2048 && c.nbs * segChunks <= 64 && KA / 32 <= 2048) {
                 std::vector<float> hw((size_t)nw);
                 std::vector<int> kl;
                 if (hipMemcpy(hw.data(), c.W, (size_t)nw * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return bail(fail("copy failed"));
