@@ -264,6 +264,12 @@ int surfh_gemm_selftest(int32_t device, int32_t M, int32_t N, int32_t K, int32_t
 /* (tile, K step) pairs the last two-piece fp16 self-test (SURFH_SELFTEST_F16X2=2: with K-step lists, as the spectral-blur
  * GEMMs of a plan) ran with all three products / with the leading product only */
 int surfh_gemm_selftest_ksteps(int64_t near_far[2]);
+/* host only (no GPU): the K-step classes the spectral-blur GEMMs of a plan would use for the constant operand B [n][ldb]
+ * (k columns, k % 32 == 0): records[(tile) * (2 + k / 32)] = n_near, n_far, near steps ascending, far steps ascending
+ * (entry = step | segment << 16).  perm_p / perm_lin: the adjoint's tile shape (0: tiles of 256 consecutive rows).
+ * Returns the number of tiles, or a negative error.                                                                     */
+int32_t surfh_klist_classify(const float *B, int32_t n, int32_t k, int64_t ldb, int32_t perm_p, int32_t perm_lin,
+                             int32_t *records, int64_t capacity);
 
 /* ---- masked linear mixing model (MixingST, surfh/Models/mixing.py:276-337; kernels c_fast_forward_TST,
  * c_fast_adjoint_TST, c_precompute_TST of surfh/ToolsDir/cythons_files.pyx:370-463) ----

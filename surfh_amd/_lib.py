@@ -53,7 +53,7 @@ EXPORTS = [
     "surfh_adjoint_spec_dev", "surfh_normal_spec_dev", "surfh_prior_spec_add_dev", "surfh_set_prior", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_cg_iter_dev", "surfh_residual_dev",
     "surfh_cg_begin_dev", "surfh_cg_iter_nosync_dev", "surfh_cg_xupdate_nosync_dev", "surfh_cg_refresh_nosync_dev", "surfh_cg_trace",
     "surfh_profile_enable", "surfh_profile_filter", "surfh_profile_count", "surfh_profile_get", "surfh_profile_reset", "surfh_debug_copy",
-    "surfh_debug_dims", "surfh_gemm_selftest", "surfh_gemm_selftest_ksteps",
+    "surfh_debug_dims", "surfh_gemm_selftest", "surfh_gemm_selftest_ksteps", "surfh_klist_classify",
 ]
 
 _lib = None
@@ -130,6 +130,8 @@ def load():
     L.surfh_debug_dims.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.surfh_gemm_selftest.argtypes = [C.c_int32] * 5 + [c_float_p, c_float_p, c_float_p]
     L.surfh_gemm_selftest_ksteps.argtypes = [C.POINTER(C.c_int64)]
+    L.surfh_klist_classify.argtypes = [c_float_p, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int64]
+    L.surfh_klist_classify.restype = C.c_int32
     _lib = L
     return L
 

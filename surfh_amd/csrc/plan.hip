@@ -2610,6 +2610,20 @@ int64_t surfh_debug_copy(surfh_plan *p, const char *which, float *out, int64_t c
     return n;
 }
 
+int32_t surfh_klist_classify(const float *B, int32_t n, int32_t k, int64_t ldb, int32_t perm_p, int32_t perm_lin, int32_t *records,
+                             int64_t capacity) {
+    if (!B || !records || n < 1 || k < 32 || k % 32 || ldb < k) return -fail("surfh_klist_classify: bad arguments");
+    if (perm_p && ((perm_p != 1 && perm_p != 2 && perm_p != 4 && perm_p != 8) || perm_lin < 1 || perm_lin % (256 / perm_p) || n % perm_lin))
+        return -fail("surfh_klist_classify: bad tile shape");
+    std::vector<int> kl;
+    int stride = 0;
+    long nn = 0, nf = 0;
+    build_klist(B, n, k, ldb, 0, 0, 1.0 / 256, 1.0 / 1024, &kl, &stride, &nn, &nf, perm_p, perm_lin);
+    if ((int64_t)kl.size() > capacity) return -fail("surfh_klist_classify: capacity too small");
+    std::memcpy(records, kl.data(), kl.size() * sizeof(int));
+    return (int32_t)(kl.size() / (size_t)stride);
+}
+
 static long g_selftest_ksteps[2] = {0, 0};
 int surfh_gemm_selftest_ksteps(int64_t near_far[2]) {
     near_far[0] = g_selftest_ksteps[0]; near_far[1] = g_selftest_ksteps[1];
