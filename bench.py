@@ -73,7 +73,7 @@ def cpu_baseline(cfg_name: str, budget_s: float):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200, help="timed CG iterations (>= 200: the timed region is >= 1 s and holds the residual refreshes of qmm.lcg, one every 50 iterations)")
+    ap.add_argument("--steps", type=int, default=400, help="timed CG iterations (400 x 3 ms: the timed region is >= 1 s and holds the residual refreshes of qmm.lcg, one every 50 iterations)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="3", choices=["2", "3"])
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")

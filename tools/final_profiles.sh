@@ -26,7 +26,7 @@ cp "$out/pmc_traffic_config3.json" "profiles/${tag}_pmc_traffic_config3.json"   
 find "$out/stats" -name "*kernel_stats.csv" -exec cp {} "$out/kernel_stats_config3.csv" \;
 python3 bench.py --config 3 > "$out/bench_config3.json" 2> "$out/bench_config3.err"
 echo "bench config 3 done"
-python3 bench.py --config 2 --steps 60 --cpu-seconds 15 > "$out/bench_config2.json" 2> "$out/bench_config2.err"
+python3 bench.py --config 2 --steps 1200 --cpu-seconds 15 > "$out/bench_config2.json" 2> "$out/bench_config2.err"
 echo "bench config 2 done"
 rm -rf "$out/stats" "$out/fetch" "$out/write"                                      # raw traces stay on the box
 ls -la "$out"
