@@ -119,13 +119,14 @@ class QuadCriterion_MRS:
 # ------------------------------------------------------------------------------------------------
 def band_cost(n_pix: int, geo) -> float:
     """Estimated time (microseconds) of one band per CG iteration, from the rates measured on MI355X
-    (profiles/r01_final_bench_config3.json): R/R^T at 285 TFLOP/s algorithmic, the two folded 2-D transforms at
-    0.63 us per owned plane (251^2, scaled by N^3), gather/scatter/spectral mix/clear/slab sum at 0.39 us per plane."""
+    (profiles/r02_bench_config3.json): R/R^T at 445 TFLOP/s algorithmic, the two folded 2-D transforms at
+    0.30 us per plane of the band's window (251^2, scaled by N^3; 1.42 ms for the 4743 window planes of config 3),
+    gather / scatter / slab sum at 0.143 us per plane."""
     P, S, Ldet, aout = geo.oshape
     Lin = geo.wslice.stop - geo.wslice.start
     nbs = geo.slicer.npix_slit_beta_width
     r_flops = 4.0 * P * S * Ldet * Lin * nbs * aout
-    return r_flops / 285e6 + Lin * 0.63 * (n_pix / 251.0) ** 3 + Lin * 0.39 * (n_pix / 251.0) ** 2 * (P / 4.0)
+    return r_flops / 445e6 + Lin * 0.30 * (n_pix / 251.0) ** 3 + Lin * 0.143 * (n_pix / 251.0) ** 2 * (P / 4.0)
 
 
 def partition_lambda(costs: Sequence[float], world: int) -> List[List[Tuple[int, Tuple[int, int]]]]:
