@@ -216,6 +216,42 @@ def partition_units(costs: Sequence[float], n_pointings: Sequence[int], world: i
     return out
 
 
+def unit_share(lins, k, u) -> float:
+    """Fraction of band k's cost a lambda unit u carries: (0, 1) whole band, (i, n) one of n equal parts, ("planes", a, b) a plane range."""
+    return 1.0 if u == (0, 1) else ((u[2] - u[1]) / lins[k] if len(u) == 3 else 1.0 / u[1])
+
+
+def choose_lambda_assignment(costs, lins, ybytes, world):
+    """Whole bands / equal parts of a band (``partition_lambda``) or equal-cost contiguous chunks (``partition_balanced``)?
+    Default (predicted per-rank cost within 15 %): whole bands / equal parts when that is already balanced to 5 %,
+    else the contiguous chunks.  ``SURFH_PARTITION=comm``: whichever has the smaller predicted time of its slowest rank with the
+    group-local all-reduces counted -- for every band a rank shares with others, 20 us + 2 (m - 1) / m * bytes of that band's
+    partial outputs at 50 GB/s (one xGMI link per pair).  The contiguous chunks put most ranks into TWO such groups: by this
+    model config 3 on 8 ranks takes 721 us per iteration with them and 655 us with two equal parts per band (compute 377 vs
+    up to 465 us) -- unmeasured, so not the default.  Returns (assignment, per-rank compute loads, per-rank predicted time)."""
+    def timed(asg):
+        members = {}
+        for r, units in enumerate(asg):
+            for k, u in units:
+                members.setdefault(k, set()).add(r)
+        loads, times = [], []
+        for r, units in enumerate(asg):
+            load = sum(costs[k] * unit_share(lins, k, u) for k, u in units)
+            comm = 0.0
+            for k in {k for k, _ in units}:
+                m = len(members[k])
+                if m > 1:
+                    comm += 20.0 + 2.0 * (m - 1) / m * ybytes[k] / 50e3
+            loads.append(load)
+            times.append(load + comm)
+        return loads, times
+    cand, bal = partition_lambda(costs, world), partition_balanced(costs, lins, world)
+    (lc, tc), (lb, tb) = timed(cand), timed(bal)
+    if os.environ.get("SURFH_PARTITION", "balanced") == "comm":
+        return (cand, lc, tc) if max(tc) <= max(tb) else (bal, lb, tb)
+    return (cand, lc, tc) if max(lc) <= 1.05 * max(lb) else (bal, lb, tb)
+
+
 def plan_assignment(prob: dict, world: int, split: str = "lambda"):
     """The unit assignment ``DistributedFusion`` uses for `world` ranks, with the predicted cost of every rank:
     ``(assignment, loads, imbalance)``, imbalance = max load / mean load - 1 (SURVEY.md 8e gate: <= 15 %).  Host only."""
@@ -228,11 +264,8 @@ def plan_assignment(prob: dict, world: int, split: str = "lambda"):
     costs = [band_cost(n_pix, g) for g in geos]
     if split == "lambda":
         lins = [g.wslice.stop - g.wslice.start for g in geos]
-        share = lambda k, u: costs[k] * (1.0 if u == (0, 1) else ((u[2] - u[1]) / lins[k] if len(u) == 3 else 1.0 / u[1]))   # noqa: E731
-        cand, bal = partition_lambda(costs, world), partition_balanced(costs, lins, world)
-        load = lambda asg: [sum(share(k, u) for k, u in r) for r in asg]                                                   # noqa: E731
-        asg = cand if max(load(cand)) <= 1.05 * max(load(bal)) else bal
-        loads = load(asg)
+        ybytes = [4 * int(np.prod(g.oshape)) for g in geos]
+        asg, loads, _ = choose_lambda_assignment(costs, lins, ybytes, world)
     else:
         asg = partition_units(costs, [len(p) for p in pts], world)
         loads = [sum(costs[k] * len(sel) / len(pts[k]) for k, sel in r) for r in asg]
@@ -266,13 +299,10 @@ class DistributedFusion:
         self.unit_groups = []          # (first, last) offsets in this rank's y and the process group, per shared band
         if split == "lambda":
             lins = [g.wslice.stop - g.wslice.start for g in geos]
-            cand = partition_lambda(self.costs, world)
-            load = lambda asg: max(sum(self.costs[k] * (1.0 if u == (0, 1) else
-                                                         ((u[2] - u[1]) / lins[k] if len(u) == 3 else 1.0 / u[1]))
-                                       for k, u in r) for r in asg)
-            bal = partition_balanced(self.costs, lins, world)
-            # whole bands (or equal parts) when that is already balanced, else equal-cost contiguous chunks
-            self.assignment = cand if load(cand) <= 1.05 * load(bal) else bal
+            ybytes = [4 * int(np.prod(g.oshape)) for g in geos]
+            # whole bands / equal parts, or equal-cost contiguous chunks: whichever predicts the faster slowest rank, the
+            # group-local all-reduces of shared bands included
+            self.assignment, _, self.predicted_us = choose_lambda_assignment(self.costs, lins, ybytes, world)
             self.units = self.assignment[rank]
             my_ifus = [ifus[k] for k, _ in self.units]
             my_pts = [pts[k] for k, _ in self.units]
