@@ -668,7 +668,7 @@ __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *
     const float osc = (kb == 0 || 2 * kb == Nb) ? out_self : out_pair;
     const float pcb = prior_src ? 2.f - 2.f * cospif(2.f * (float)kb / (float)Nb) : 0.f;
     if (kb >= hb) {
-        for (int i = threadIdx.x; i < KAP * 8; i += 256) {
+        for (int i = blockIdx.y * 256 + threadIdx.x; i < KAP * 8; i += 256 * gridDim.y) {
             const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
             if (t < T) madj[((long)t * 2 + c) * PL + (long)row * KBP + kb] = 0.f;
         }
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(256) void dft_h2_adjmix_reduce_kernel(const float *
         bl = b;
     }
     const int ns = hi <= lo ? 0 : ((bl - bf + 1) * 8 < nslot ? (bl - bf + 1) * 8 : nslot);      // a k_beta without tiles: zero
-    for (int i = threadIdx.x; i < KAP * 8; i += 256) {
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < KAP * 8; i += 256 * gridDim.y) {      // gridDim.y blocks share a k_beta: the sums are short chains of loads
         const int row = i >> 3, tc = i & 7, t = tc >> 1, c = tc & 1;
         if (t >= T) continue;
         float s = 0.f;
@@ -829,7 +829,7 @@ int launch_dft_h2_adjmix(hipStream_t stream, const DftH2Args &g, const DftH2AdjM
     if (int e = ensure_dynamic_lds(dft_h2_adjmix_kernel, ldsb, d4)) return e;
     hipLaunchKernelGGL(dft_h2_adjmix_kernel, dim3((unsigned)G), dim3(NTHREADS), ldsb, stream, g, am, reinterpret_cast<const uint4 *>(img), kA, (int)NS);
     if (hipError_t e = hipGetLastError(); e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(dft_h2_adjmix_reduce_kernel, dim3((unsigned)KBP), dim3(256), 0, stream, am.mpart, madj, nslot, am.T, g.Rn, (int)(PL / KBP),
+    hipLaunchKernelGGL(dft_h2_adjmix_reduce_kernel, dim3((unsigned)KBP, 8), dim3(256), 0, stream, am.mpart, madj, nslot, am.T, g.Rn, (int)(PL / KBP),
                        g.batch, KBP, PL, (int)NS, G / 2, (int)(g.N / 16 / 8), am.out_self, am.out_pair, am.Nb, am.prior_src, am.prior_mu, am.kbstart);
     return (int)hipGetLastError();
 }
