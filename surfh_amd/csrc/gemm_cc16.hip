@@ -173,8 +173,28 @@ __device__ __forceinline__ void cc16_unit(f32x4v (&acc)[4][8], f16x8 (&A)[4][2],
 constexpr int CC2_MAXLIST = 2048;                                     // K steps of one slab (launcher checks)
 constexpr size_t LDS3_BYTES = LDS2_BYTES + (size_t)CC2_MAXLIST * sizeof(int);
 
-__global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
+// The products of one launch: work items (tile, slab, batch entry) of product i are first[i] .. first[i + 1] - 1 of one list,
+// and XCD x takes a contiguous eighth of that list -- the products run side by side, each on the XCDs its items fall to.
+// Measured on config 3 (four bands): the adjoint's products, 1.5-1.8 rounds of workgroups each on their own, 0.52 -> 0.41 ms per
+// step (0.43 with the products one after the other inside the launch, each spread over all XCDs); the forward's products are
+// one full round each and lose the L2 sharing of 252 concurrent workgroups on the same operands: 0.40 -> 0.51 ms -- they
+// stay one launch per channel.
+struct GemmGroup {
+    GemmArgs g[GEMM_GROUP_MAX];
+    long first[GEMM_GROUP_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmGroup grp) {
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
+    // XCD x takes a contiguous range of the launch's work items (workgroups sharing an L2 share their operands)
+    const long gtotal = grp.first[grp.n], per = (gtotal + 7) / 8;
+    const long vg = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if ((long)(blockIdx.x >> 3) >= per || vg >= gtotal) return;
+    int gi = 0;
+    while (gi + 1 < grp.n && vg >= grp.first[gi + 1]) ++gi;
+    const long v = vg - grp.first[gi];
+    const GemmArgs g = grp.g[gi];
     unsigned char *sctab = reinterpret_cast<unsigned char *>(lds + 2 * STAGE);     // [segment][256 rows] exponent fields of A's block scales
     int *klds = reinterpret_cast<int *>(sctab + CC2_MAXSEG * BM);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -187,9 +207,6 @@ __global__ __launch_bounds__(512, 1) void gemm_nt_f16x2_cc_kernel(GemmArgs g) {
         const int c = (tn_ / tilesL) * g.permP + v / Q;
         return c < ncol ? c * g.permLin + (tn_ % tilesL) * Q + v % Q : -1;
     };
-    const long total = (long)tiles * g.splitK * g.batch, per = (total + 7) / 8;
-    const long v = (long)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if ((long)(blockIdx.x >> 3) >= per || v >= total) return;
     const int t = (int)(v % tiles), z = (int)(v / tiles);
     const int tm = t % tilesM, tn = t / tilesM;
     const int b = z / g.splitK, sk = z % g.splitK;
@@ -465,7 +482,8 @@ int launch_split_rows2h(hipStream_t stream, const float *src, const unsigned *ro
 }
 
 // A as fp16 pieces A3[q*pA3 + m*lda + k] of A[m][k] / scale(amax[m]) (launch_split_rows2h), B as pieces B16 of B / sB16
-int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g) {
+// argument checks of one product; *items = its work items (tiles x slabs x batch entries)
+static int check_gemm_nt_f16x2_cc(const GemmArgs &g, long *items) {
     if (g.M % 64 || g.N % 128 || g.K % (BK * g.splitK) || g.splitK < 1 || g.batch < 1 || g.accumulate || g.lda % 8 || g.ldb % 8 || !g.A3 ||
         !g.B16 || g.pA3 % 8 || g.pB16 % 8 || (!g.amax && !g.bscale) || !(g.sB16 > 0.f))
         return (int)hipErrorInvalidValue;
@@ -492,10 +510,29 @@ int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g) {
             return (int)hipErrorInvalidValue;
         tilesN = (long)((g.N / g.permLin + g.permP - 1) / g.permP) * (g.permLin / (BN / g.permP));
     }
-    const long total = (long)((g.M + BM - 1) / BM) * tilesN * g.batch * g.splitK;
+    *items = (long)((g.M + BM - 1) / BM) * tilesN * g.batch * g.splitK;
+    return 0;
+}
+
+int launch_gemm_nt_f16x2_cc_group(hipStream_t stream, const GemmArgs *gs, int n) {
+    if (n < 1 || n > GEMM_GROUP_MAX) return (int)hipErrorInvalidValue;
+    GemmGroup grp;
+    grp.n = n;
+    grp.first[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        long items = 0;
+        if (int e = check_gemm_nt_f16x2_cc(gs[i], &items)) return e;
+        grp.g[i] = gs[i];
+        grp.first[i + 1] = grp.first[i] + items;
+    }
+    for (int i = n; i < GEMM_GROUP_MAX; ++i) grp.first[i + 1] = grp.first[n];
+    const long total = grp.first[n];
+    if (total >= 2147483647L - 8) return (int)hipErrorInvalidValue;
     dim3 grid((unsigned)(8 * ((total + 7) / 8)));
     static unsigned long long attr_done = 0;
     if (int e = ensure_dynamic_lds(gemm_nt_f16x2_cc_kernel, LDS3_BYTES, attr_done)) return e;
-    hipLaunchKernelGGL(gemm_nt_f16x2_cc_kernel, grid, dim3(512), LDS3_BYTES, stream, g);
+    hipLaunchKernelGGL(gemm_nt_f16x2_cc_kernel, grid, dim3(512), LDS3_BYTES, stream, grp);
     return (int)hipGetLastError();
 }
+
+int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g) { return launch_gemm_nt_f16x2_cc_group(stream, &g, 1); }

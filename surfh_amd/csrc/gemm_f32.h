@@ -57,4 +57,8 @@ float gemm_f16x2_scale(float amax);
 // operands as fp16 pieces delivered by LDS-DMA.  M multiple of 64, N of 128, K of 32 * splitK.
 // A3 / pA3 = pieces of A split row by row with the scales of amax[M] (launch_split_rows2h); B16 / pB16 / sB16 as above.
 int launch_gemm_nt_f16x2_cc(hipStream_t stream, const GemmArgs &g);
+// several such products in ONE launch (n <= 4): their tiles fill the rounds of workgroups together (the adjoint spectral-blur
+// GEMMs of the bands are 1.5-1.8 rounds each on their own)
+constexpr int GEMM_GROUP_MAX = 4;
+int launch_gemm_nt_f16x2_cc_group(hipStream_t stream, const GemmArgs *g, int n);
 int launch_split_rows2h(hipStream_t stream, const float *src, const unsigned *rowmax, unsigned short *dst2, int rows, int ld, long plane);

@@ -152,6 +152,7 @@ struct surfh_plan {
     int n_cu = 256;
     int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
     bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
+    bool gemm_grouped = true;                    // the adjoint's spectral-blur GEMMs of up to four channels as one launch (SURFH_GEMM_GROUPED=0: one each)
     bool scatter_grouped = true;                 // adjoint scatter with SCATTER_G neighbouring pixels per workgroup (GroupTable)
     bool gather_grouped = true;                  // forward gather (fp16 output) likewise
     bool dense_dft = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
@@ -1243,7 +1244,50 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
         Prof pr(p, "fill_zero");
         LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
     }
-    for (auto &c : p->ch) {
+    // The two-piece fp16 GEMMs of up to four channels go out as ONE launch (each is 1.5-1.8 rounds of workgroups on its own;
+    // their operands and outputs are per channel, so nothing orders them among themselves): detector-side preparation of all
+    // of them first, the grouped GEMM, then the scatters in channel order.  SURFH_GEMM_GROUPED=0: one launch per channel.
+    std::vector<char> gemm_done(p->ch.size(), 0);
+    {
+        const bool grouped = p->gemm_grouped;
+        std::vector<GemmArgs> ga;
+        std::vector<size_t> gc;
+        auto flush = [&]() -> int {
+            if (ga.empty()) return 0;
+            {
+                Prof pr(p, "gemm_wblur_adj", sB);
+                LAUNCH_OK(launch_gemm_nt_f16x2_cc_group(sB, ga.data(), (int)ga.size()));
+            }
+            for (size_t i : gc) gemm_done[i] = 1;
+            ga.clear(); gc.clear();
+            return 0;
+        };
+        for (size_t ci = 0; grouped && !p->wblur_fp32 && !p->verify && ci < p->ch.size(); ++ci) {
+            Channel &c = p->ch[ci];
+            if (c.bsum || !c.W16 || (ref && !c.has_ref)) continue;
+            const bool have16 = handed_over && c.ymat16;
+            if (!have16) {
+                {
+                    Prof pr(p, "ymat_from_y", sB);
+                    LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, c.pmax, c.amax, c.NP));
+                }
+                LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
+            }
+            GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
+            g.lda = c.LdetP; g.C = c.Xs; g.ldc = c.K; g.M = c.NP; g.N = c.K;
+            g.K = (c.Ldet + 31) / 32 * 32;           // the columns of ymat beyond Ldet are zero: whole K steps of them are skipped
+            g.ldb = c.LdetP;                         // B as [N'=k][K'=l']
+            g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
+            g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
+            g.klist = c.klA; g.klistStride = c.klAs;
+            if (c.klA && c.permA) { g.permP = c.permA; g.permLin = c.LinP; }
+            ga.push_back(g); gc.push_back(ci);
+            if ((int)ga.size() == GEMM_GROUP_MAX && flush()) return 1;
+        }
+        if (flush()) return 1;
+    }
+    for (size_t ci = 0; ci < p->ch.size(); ++ci) {
+        Channel &c = p->ch[ci];
         if (ref && !c.has_ref) return fail("adjoint_ref needs the gridding_t tables (gt_*) in the channel descriptor");
         if (c.bsum) {
             {
@@ -1261,6 +1305,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
         }
         const bool f16 = c.W16 != nullptr;
         const bool have16 = handed_over && f16 && c.ymat16;
+        if (!gemm_done[ci]) {
         if (!have16) {
             Prof pr(p, "ymat_from_y", sB);
             LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax : nullptr,
@@ -1285,6 +1330,7 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
                 if (c.klA && c.permA) { g.permP = c.permA; g.permLin = c.LinP; }
                 LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
             }
+        }
         }
         if (chain(p, sB, s)) return 1;
         {
@@ -1561,6 +1607,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e15 = getenv("SURFH_GATHER_GROUPED");
         p->gather_grouped = !(e15 && e15[0] == '0');
+        { const char *eg = getenv("SURFH_GEMM_GROUPED"); p->gemm_grouped = !(eg && eg[0] == '0'); }
         const char *e14 = getenv("SURFH_SCATTER_GROUPED");
         p->scatter_grouped = !(e14 && e14[0] == '0');
         const char *e12 = getenv("SURFH_GATHER_SORTED");

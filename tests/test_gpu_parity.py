@@ -490,11 +490,13 @@ def test_disjoint_wavelength_windows(lmm):
                                  {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_H2": "0", "SURFH_DFT_PACKED": "0"}, {"SURFH_DFT_H2": "0"},
                                  {"SURFH_GATHER_SORTED": "0"}, {"SURFH_SCATTER_RMW_ALL": "1"}, {"SURFH_SCATTER_GROUPED": "0"},
                                  {"SURFH_GATHER_GROUPED": "0"}, {"SURFH_ALPHA_RANGE": "0"}, {"SURFH_ADJ_FUSED": "0"}, {"SURFH_ADJ_CLEAR": "1"},
-                                 {"SURFH_WBLUR_FAR": "0"}, {"SURFH_WBLUR_PERM": "0"}, {"SURFH_OTF_SUPPORT": "0"}, {"SURFH_OTF_RANGES": "0"}],
+                                 {"SURFH_WBLUR_FAR": "0"}, {"SURFH_WBLUR_PERM": "0"}, {"SURFH_OTF_SUPPORT": "0"}, {"SURFH_OTF_RANGES": "0"},
+                                 {"SURFH_GEMM_GROUPED": "0"}],
                          ids=["fold_fp32", "dense_dft", "unfused_mix", "wblur_fp32", "two_streams", "dft_bf16_two_pass_complex",
                               "dft_bf16_three_piece", "gather_rows_unsorted", "scatter_rmw_everywhere", "scatter_row_by_row",
                               "gather_row_by_row", "transform_whole_cube", "adjoint_tail_separate", "adjoint_clears_accumulator",
-                              "gemm_three_products_everywhere", "gemm_adjoint_plain_tiles", "whole_spectrum", "otf_support_lists_only"])
+                              "gemm_three_products_everywhere", "gemm_adjoint_plain_tiles", "whole_spectrum", "otf_support_lists_only",
+                              "adjoint_gemms_one_by_one"])
 def test_alternative_kernel_paths(env):
     """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green."""
     cfg = problems.config1()
