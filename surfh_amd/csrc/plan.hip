@@ -1244,47 +1244,60 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
         Prof pr(p, "fill_zero");
         LAUNCH_OK(launch_fill_zero(s, p->cube, (long)p->NBP * p->NAP * p->LP));
     }
-    // The two-piece fp16 GEMMs of up to four channels go out as ONE launch (each is 1.5-1.8 rounds of workgroups on its own;
-    // their operands and outputs are per channel, so nothing orders them among themselves): detector-side preparation of all
-    // of them first, the grouped GEMM, then the scatters in channel order.  SURFH_GEMM_GROUPED=0: one launch per channel.
-    std::vector<char> gemm_done(p->ch.size(), 0);
-    {
-        const bool grouped = p->gemm_grouped;
-        std::vector<GemmArgs> ga;
-        std::vector<size_t> gc;
-        auto flush = [&]() -> int {
-            if (ga.empty()) return 0;
-            {
-                Prof pr(p, "gemm_wblur_adj", sB);
-                LAUNCH_OK(launch_gemm_nt_f16x2_cc_group(sB, ga.data(), (int)ga.size()));
-            }
-            for (size_t i : gc) gemm_done[i] = 1;
-            ga.clear(); gc.clear();
-            return 0;
-        };
-        for (size_t ci = 0; grouped && !p->wblur_fp32 && !p->verify && ci < p->ch.size(); ++ci) {
-            Channel &c = p->ch[ci];
-            if (c.bsum || !c.W16 || (ref && !c.has_ref)) continue;
-            const bool have16 = handed_over && c.ymat16;
-            if (!have16) {
-                {
-                    Prof pr(p, "ymat_from_y", sB);
-                    LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, c.pmax, c.amax, c.NP));
-                }
-                LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
-            }
-            GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
-            g.lda = c.LdetP; g.C = c.Xs; g.ldc = c.K; g.M = c.NP; g.N = c.K;
-            g.K = (c.Ldet + 31) / 32 * 32;           // the columns of ymat beyond Ldet are zero: whole K steps of them are skipped
-            g.ldb = c.LdetP;                         // B as [N'=k][K'=l']
+    // detector side of one channel: y -> ymat (-> its fp16 pieces, unless the forward half has just left them behind)
+    auto prepare = [&](Channel &c) -> int {
+        const bool f16 = c.W16 != nullptr;
+        if (handed_over && f16 && c.ymat16) return 0;
+        {
+            Prof pr(p, "ymat_from_y", sB);
+            LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax : nullptr,
+                                         f16 ? c.amax : nullptr, c.NP));
+        }
+        if (f16 && !p->wblur_fp32)
+            LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
+        return 0;
+    };
+    auto gemm_args = [&](Channel &c) {   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
+        GemmArgs g;
+        g.A0 = c.ymat; g.lda = c.LdetP;
+        g.C = c.Xs; g.ldc = c.K;
+        g.M = c.NP; g.N = c.K; g.K = c.LdetP;
+        if (p->wblur_fp32) {
+            g.B0 = c.W; g.ldb = c.K;             // B as [K'=l'][N'=k]
+        } else if (c.W16) {
+            g.K = (c.Ldet + 31) / 32 * 32;       // the columns of ymat beyond Ldet are zero: whole K steps of them are skipped
+            g.ldb = c.LdetP;                     // B as [N'=k][K'=l']
             g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
             g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
             g.klist = c.klA; g.klistStride = c.klAs;
             if (c.klA && c.permA) { g.permP = c.permA; g.permLin = c.LinP; }
-            ga.push_back(g); gc.push_back(ci);
-            if ((int)ga.size() == GEMM_GROUP_MAX && flush()) return 1;
         }
-        if (flush()) return 1;
+        return g;
+    };
+    // The two-piece fp16 GEMMs of up to four channels go out as ONE launch (each is 1.5-1.8 rounds of workgroups on its own;
+    // their operands and outputs are per channel, so nothing orders them among themselves): detector-side preparation of all
+    // of them first, the grouped GEMM, then the scatters in channel order.  SURFH_GEMM_GROUPED=0: one launch per channel.
+    std::vector<char> gemm_done(p->ch.size(), 0);
+    if (p->gemm_grouped && !p->wblur_fp32 && !p->verify) {
+        std::vector<GemmArgs> ga;
+        std::vector<size_t> gc;
+        for (size_t ci = 0; ci <= p->ch.size(); ++ci) {
+            const bool last = ci == p->ch.size();
+            if (!last) {
+                Channel &c = p->ch[ci];
+                if (c.bsum || !c.W16 || (ref && !c.has_ref)) continue;
+                if (prepare(c)) return 1;
+                ga.push_back(gemm_args(c)); gc.push_back(ci);
+            }
+            if (!ga.empty() && (last || (int)ga.size() == GEMM_GROUP_MAX)) {
+                {
+                    Prof pr(p, "gemm_wblur_adj", sB);
+                    LAUNCH_OK(launch_gemm_nt_f16x2_cc_group(sB, ga.data(), (int)ga.size()));
+                }
+                for (size_t i : gc) gemm_done[i] = 1;
+                ga.clear(); gc.clear();
+            }
+        }
     }
     for (size_t ci = 0; ci < p->ch.size(); ++ci) {
         Channel &c = p->ch[ci];
@@ -1303,34 +1316,12 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
                 LAUNCH_OK(launch_spmm_rows(s, ref ? c.adjRef.t : c.adjT.t, c.Xs, acc, c.nlam, 1));
             continue;
         }
-        const bool f16 = c.W16 != nullptr;
-        const bool have16 = handed_over && f16 && c.ymat16;
         if (!gemm_done[ci]) {
-        if (!have16) {
-            Prof pr(p, "ymat_from_y", sB);
-            LAUNCH_OK(launch_ymat_from_y(sB, y + c.yoff, c.ymat, c.P * c.S, c.Ldet, c.aout, c.LdetP, f16 ? c.pmax : nullptr,
-                                         f16 ? c.amax : nullptr, c.NP));
-        }
-        GemmArgs g;   // Xs_t[n][k] = sum_l' y^T[n][l'] W[l'][k]
-        g.A0 = c.ymat; g.lda = c.LdetP;
-        g.C = c.Xs; g.ldc = c.K;
-        g.M = c.NP; g.N = c.K; g.K = c.LdetP;
-        if (f16) g.K = (c.Ldet + 31) / 32 * 32;      // the columns of ymat beyond Ldet are zero: whole K steps of them are skipped
-        {
+            if (prepare(c)) return 1;
+            const GemmArgs g = gemm_args(c);
             Prof pr(p, "gemm_wblur_adj", sB);
-            if (p->wblur_fp32) {
-                g.B0 = c.W; g.ldb = c.K;             // B as [K'=l'][N'=k]
-                LAUNCH_OK(gemm32(p, sB, g));
-            } else {
-                g.ldb = c.LdetP;                     // B as [N'=k][K'=l']
-                g.B16 = c.Wt16; g.pB16 = (long)c.LdetP * c.K; g.sB16 = c.sW; g.amax = c.amax;
-                if (!have16) LAUNCH_OK(launch_split_rows2h(sB, c.ymat, c.amax, c.ymat16, c.NP, c.LdetP, (long)c.NP * c.LdetP));   // one scale per row
-                g.A3 = c.ymat16; g.pA3 = (long)c.NP * c.LdetP;
-                g.klist = c.klA; g.klistStride = c.klAs;
-                if (c.klA && c.permA) { g.permP = c.permA; g.permLin = c.LinP; }
-                LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
-            }
-        }
+            if (p->wblur_fp32 || !c.W16) LAUNCH_OK(gemm32(p, sB, g));
+            else LAUNCH_OK(launch_gemm_nt_f16x2_cc(sB, g));
         }
         if (chain(p, sB, s)) return 1;
         {
