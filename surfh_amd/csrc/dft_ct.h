@@ -39,7 +39,7 @@ struct DftCtArgs {
     long ldb = 0, sB = 0;                      // row pitch / batch stride of src, in floats
     float *dst = nullptr;
     long ldc = 0, sC = 0;
-    int ncols = 0;                             // complex (or packed) columns per batch entry, % 128 == 0
+    int ncols = 0;                             // complex (or packed) columns per batch entry, % 64 == 0 (% 128 with a list of super-tiles)
     int batch = 1;
     // MIX loader (column n = kb * LP + l, or batch entry = kb when batch > 1)
     const float *mhat = nullptr, *tpl = nullptr;

@@ -578,7 +578,7 @@ void dft_ct_plan_destroy(DftCtPlan *p) {
 }
 
 int launch_dft_ct(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl) {
-    if (!pl.img || !pl.tw || g.R != pl.R || g.M != pl.M || !g.src || !g.dst || g.ncols < 128 || g.ncols % 128 || g.batch < 1)
+    if (!pl.img || !pl.tw || g.R != pl.R || g.M != pl.M || !g.src || !g.dst || g.ncols < 64 || g.ncols % 64 || g.batch < 1)
         return (int)hipErrorInvalidValue;
     if (g.loader == DFT_CT_MIX && (!g.mhat || !g.tpl || g.T < 1 || g.T > 4 || g.LP % 128)) return (int)hipErrorInvalidValue;
     if ((g.loader == DFT_CT_HPACK && g.sgn < 0.f) || (g.epi == DFT_CT_HSEP && g.sgn > 0.f)) return (int)hipErrorInvalidValue;
@@ -598,7 +598,7 @@ int launch_dft_ct(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl) {
     long NU = (long)(g.ncols / (16 * NG)) * g.batch;
     if (g.vlist) {
         const long NS = (long)(g.ncols / 128) * g.batch;
-        if (g.nvalid < 1 || g.nvalid > NS) return (int)hipErrorInvalidValue;
+        if (g.ncols % 128 || g.nvalid < 1 || g.nvalid > NS) return (int)hipErrorInvalidValue;
         NU = (long)g.nvalid * (128 / (16 * NG));
     }
     if (NU >= 2147483647L / 16) return (int)hipErrorInvalidValue;

@@ -34,6 +34,7 @@
 #include "dft_fold.h"
 #include "dft_rx3.h"
 #include "dft_h2.h"
+#include "dft_ct.h"
 #include "gemm_f32.h"
 #include "kernels.h"
 
@@ -164,6 +165,10 @@ struct surfh_plan {
     // mhat when T == 0) are then INTERLEAVED [..][LP][2] instead of planar [2][..][LP]
     bool h2 = false;
     unsigned short *h2img = nullptr;             // three images: (Cma, Sma), (Gc, Gs), (Cf, Sf)
+    // Cooley-Tukey passes (dft_ct.h) for lengths whose folded matrix does not fit LDS (N = R * M: 501, 512, ...); same
+    // interleaved layout.  ilv = h2 || ct is the layout flag of the complex arrays.
+    bool ct = false, ilv = false;
+    DftCtPlan ctA, ctB;                          // transform lengths Na / Nb (ctB aliases ctA when they are equal)
     // cube columns alpha in [a_lo, a_hi) hold every pixel any channel's tables touch: the transform passes that are batched
     // over alpha skip the rest (forward: the cube outside is never read; adjoint: it is zero).  ycol_adj: the adjoint's
     // intermediate in its own buffer, whose columns outside the range stay zero from plan creation on.
@@ -1072,8 +1077,71 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     return 0;
 }
 
+// ---- Cooley-Tukey passes (dft_ct.h): the same four passes for N = R * M, interleaved complex arrays ---------------
+// cube [NBP][NAP][LP] -> spec [KAP][KBP][LP][2]        (tmp ycol viewed as Z[KBP][NAP][LP][2])
+int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false) {
+    const long LP = p->LP;
+    const int hb = p->Nb / 2 + 1;
+    const bool sub = acols && p->ycol_adj && p->a_hi > p->a_lo;
+    float *const yc = sub ? p->ycol_adj : p->ycol;
+    const int a0 = sub ? p->a_lo : 0, na = sub ? p->a_hi - p->a_lo : p->Na;
+    DftCtArgs g;   // r2c along beta: neighbouring wavelengths as packed pairs a + i b, separated in the epilogue
+    g.R = p->ctB.R; g.M = p->ctB.M; g.loader = DFT_CT_PLAIN; g.epi = DFT_CT_HSEP; g.sgn = -1.f;
+    g.scale = (float)(0.5 / std::sqrt((double)p->Nb));
+    g.src = src + (long)a0 * LP; g.ldb = p->NAP * LP;
+    g.dst = yc + 2 * (long)a0 * LP; g.ldc = 2 * p->NAP * LP;
+    g.ncols = (int)(na * LP / 2); g.batch = 1;
+    {
+        Prof pr(p, "dft_ct_rows_fwd");
+        LAUNCH_OK(launch_dft_ct(p->stream, g, p->ctB));
+    }
+    DftCtArgs h;   // c2c along alpha, batched over k_beta
+    h.R = p->ctA.R; h.M = p->ctA.M; h.loader = DFT_CT_PLAIN; h.epi = DFT_CT_STORE; h.sgn = -1.f;
+    h.scale = (float)(1.0 / std::sqrt((double)p->Na));
+    h.src = yc; h.ldb = 2 * LP; h.sB = 2 * p->NAP * LP;
+    h.dst = dst; h.ldc = 2 * p->KBP * LP; h.sC = 2 * LP;
+    h.ncols = (int)LP; h.batch = hb;
+    {
+        Prof pr(p, "dft_ct_cols_fwd");
+        LAUNCH_OK(launch_dft_ct(p->stream, h, p->ctA));
+    }
+    return 0;
+}
+
+// spec [KAP][KBP][LP][2] -> cube [NBP][NAP][LP]        (tmp ycol viewed as Y[NAP][KBP][LP][2])
+int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false) {
+    const long LP = p->LP;
+    const int hb = p->Nb / 2 + 1;
+    DftCtArgs g;   // c2c along alpha (optionally with the spectral mix formed in the loader)
+    g.R = p->ctA.R; g.M = p->ctA.M; g.loader = mix ? DFT_CT_MIX : DFT_CT_PLAIN; g.epi = DFT_CT_STORE; g.sgn = 1.f;
+    g.scale = (float)(1.0 / std::sqrt((double)p->Na));
+    g.src = src; g.ldb = 2 * p->KBP * LP;
+    g.dst = p->ycol; g.ldc = 2 * p->KBP * LP;
+    g.ncols = (int)(hb * LP); g.batch = 1;
+    if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
+    if (mix && p->spec_in) { g.mhat = p->spec_in; g.mhat_self = 1.f; g.mhat_pair = 0.70710678118654752f; g.mix_Nb = p->Nb; }
+    {
+        Prof pr(p, mix ? "dft_ct_cols_inv_mix" : "dft_ct_cols_inv");
+        LAUNCH_OK(launch_dft_ct(p->stream, g, p->ctA));
+    }
+    const bool sub = acols && p->a_hi > p->a_lo;
+    const int a0 = sub ? p->a_lo : 0, na = sub ? p->a_hi - p->a_lo : p->Na;
+    DftCtArgs h;   // c2r along beta, batched over alpha: two neighbouring half spectra as one Hermitian-extended complex sequence
+    h.R = p->ctB.R; h.M = p->ctB.M; h.loader = DFT_CT_HPACK; h.epi = DFT_CT_STORE; h.sgn = 1.f;
+    h.scale = (float)(1.0 / std::sqrt((double)p->Nb));
+    h.src = p->ycol + (long)a0 * 2 * p->KBP * LP; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
+    h.dst = dst + (long)a0 * LP; h.ldc = p->NAP * LP; h.sC = LP;
+    h.ncols = (int)(LP / 2); h.batch = na;
+    {
+        Prof pr(p, "dft_ct_rows_inv");
+        LAUNCH_OK(launch_dft_ct(p->stream, h, p->ctB));
+    }
+    return 0;
+}
+
 int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
     if (p->h2) return rfft2_lam_h2(p, src, dst);
+    if (p->ct) return rfft2_lam_ct(p, src, dst);
     if (p->rx3) return rfft2_lam_rx3(p, src, dst);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -1101,6 +1169,7 @@ int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
 
 int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
     if (p->h2) return irfft2_lam_h2(p, src, dst, mix, acols);
+    if (p->ct) return irfft2_lam_ct(p, src, dst, mix, acols);
     if (p->rx3) return irfft2_lam_rx3(p, src, dst, mix);
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
@@ -1139,9 +1208,9 @@ int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, b
 // `acols`: the cube is zero outside the alpha range of the channels' tables (the adjoint's accumulator)
 int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
     if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->spec_out ? p->spec_out : p->mhat, acols);
-    if (rfft2_cube(p, cube, p->spec)) return 1;
+    if (p->ct && !p->dense_dft ? rfft2_lam_ct(p, cube, p->spec, acols) : rfft2_cube(p, cube, p->spec)) return 1;
     Prof pr(p, "specmix_adj");
-    LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->h2));
+    LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->ilv));
     return 0;
 }
 
@@ -1172,7 +1241,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false)
     } else {
         {
             Prof pr(p, "specmix_fwd");
-            LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP, p->h2));
+            LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP, p->ilv));
         }
         if (irfft2_cube(p, p->spec, p->cube)) return 1;
     }
@@ -1380,7 +1449,7 @@ int ensure_hessian(surfh_plan *p) {
         hipFree(m2);
         return 1;
     }
-    const int rc = launch_wct_hessian(p->stream, p->sotf, p->tpl, h, p->T, p->PL, p->LP, p->h2);
+    const int rc = launch_wct_hessian(p->stream, p->sotf, p->tpl, h, p->T, p->PL, p->LP, p->ilv);
     if (rc != 0) {
         hipFree(h);
         hipFree(m2);
@@ -1417,6 +1486,8 @@ int surfh_plan_destroy(surfh_plan *p) {
         hipFree(v);
     hipFree(p->dft3);
     hipFree(p->h2img);
+    if (p->ctB.img != p->ctA.img) dft_ct_plan_destroy(&p->ctB);
+    dft_ct_plan_destroy(&p->ctA);
     hipFree(p->adjmix_part);
     hipFree(p->otf_vlist);
     hipFree(p->otf_kbstart);
@@ -1533,6 +1604,10 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         const char *eh = getenv("SURFH_DFT_H2"), *er = getenv("SURFH_DFT_RX3"), *ed = getenv("SURFH_DFT_DENSE");
         p->h2 = !cfg->verify && !(eh && eh[0] == '0') && !(er && er[0] == '0') && !(ed && ed[0] == '1') &&
                 dft_h2_supported(p->Na, p->Nb, p->NAP, p->KBP, p->LP);
+        const char *ec = getenv("SURFH_DFT_CT");
+        p->ct = !p->h2 && !cfg->verify && !(ec && ec[0] == '0') && !(er && er[0] == '0') && !(ed && ed[0] == '1') && p->LP % 128 == 0 &&
+                dft_ct_supported(p->Na, p->Nb);
+        p->ilv = p->h2 || p->ct;
     }
     // ---- constants ------------------------------------------------------------------------
     {   // sotf [Lc][Na][Nb/2+1] complex128  ->  [2][KAP][KBP][LP] float (h2: [KAP][KBP][LP][2]), wavelength innermost
@@ -1548,7 +1623,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                 const double *src = cfg->sotf ? cfg->sotf + ((size_t)p->planes[l] * p->Na + a) * nkb * 2 : nullptr;
                 for (int k = 0; k < nkb; ++k) {
                     const float vr = src ? (float)src[2 * k] : 1.f, vi = src ? (float)src[2 * k + 1] : 0.f;
-                    if (p->h2) {
+                    if (p->ilv) {
                         row[((size_t)k * LP + l) * 2] = vr;
                         row[((size_t)k * LP + l) * 2 + 1] = vi;
                     } else {
@@ -1557,7 +1632,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                     }
                 }
             }
-            if (p->h2) {
+            if (p->ilv) {
                 if (hipMemcpy(p->sotf + (size_t)a * p->KBP * LP * 2, row.data(), (size_t)2 * p->KBP * LP * sizeof(float),
                               hipMemcpyHostToDevice) != hipSuccess)
                     return bail(fail("sotf upload failed"));
@@ -1650,6 +1725,11 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                 const size_t npart = dft_h2_adjmix_part_floats(p->LP, p->Nb / 2 + 1, p->otf_nvalid);
                 if (npart && dev_alloc(&p->adjmix_part, npart)) return bail(1);
             }
+        }
+        if (p->ct) {   // image + twiddles per transform length (dft_ct.h)
+            if (dft_ct_plan_create(p->Na, &p->ctA)) return bail(fail("dft_ct plan (n_alpha = %d) failed", p->Na));
+            if (p->Nb == p->Na) p->ctB = p->ctA;
+            else if (dft_ct_plan_create(p->Nb, &p->ctB)) return bail(fail("dft_ct plan (n_beta = %d) failed", p->Nb));
         }
         const char *e5 = getenv("SURFH_DFT_RX3");
         p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
@@ -1752,7 +1832,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     {   // transform passes batched over alpha skip the columns no table touches (SURFH_ALPHA_RANGE=0: whole cube)
         const char *ear = getenv("SURFH_ALPHA_RANGE");
         if (ear && ear[0] == '0') { p->a_lo = 0; p->a_hi = p->Na; p->b_lo = 0; p->b_hi = p->Nb; }
-        if (p->h2 && p->a_hi - p->a_lo < p->Na) {      // the adjoint's intermediate: columns outside the range zero for good
+        if (p->ilv && p->a_hi - p->a_lo < p->Na) {      // the adjoint's intermediate: columns outside the range zero for good
             const size_t nyc = (size_t)2 * p->NAP * p->KBP * p->LP;
             if (dev_alloc(&p->ycol_adj, nyc)) return bail(1);
             if (hipMemset(p->ycol_adj, 0, nyc * sizeof(float)) != hipSuccess) return bail(fail("memset failed"));
@@ -1916,7 +1996,7 @@ int surfh_wct_forward(surfh_plan *p, const float *maps, float *cube) {
     HIP_OK(hipMemcpyAsync(p->io_x, maps, p->isize * sizeof(float), hipMemcpyHostToDevice, s));
     LAUNCH_OK(launch_pad_planes(s, p->io_x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
     if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
-    LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP, p->h2));
+    LAUNCH_OK(launch_specmix_fwd(s, p->mhat, p->sotf, p->tpl, p->spec, p->T, p->PL, p->LP, p->ilv));
     if (irfft2_cube(p, p->spec, p->cube)) return 1;
     LAUNCH_OK(launch_cube_from_lam_inner(s, p->cube, p->io_cube, 0, p->Lc, p->Na, p->Nb, p->NAP, p->LP));
     HIP_OK(hipMemcpyAsync(cube, p->io_cube, (size_t)p->Lc * p->Na * p->Nb * sizeof(float), hipMemcpyDeviceToHost, s));
@@ -2590,7 +2670,7 @@ static int resolve(surfh_plan *p, const char *which, const float **ptr, int64_t 
         *ptr = (w == "gcube" && p->gcube) ? p->gcube : p->cube; dims[0] = p->NBP; dims[1] = p->NAP; dims[2] = p->LP;
     } else if (w == "spec") {                       // [2][k_alpha][k_beta][lambda]; h2 plans: [k_alpha][k_beta][lambda][2]
         *ptr = p->spec;
-        if (p->h2) { dims[0] = p->KAP; dims[1] = p->KBP; dims[2] = p->LP; dims[3] = 2; }
+        if (p->ilv) { dims[0] = p->KAP; dims[1] = p->KBP; dims[2] = p->LP; dims[3] = 2; }
         else { dims[0] = 2; dims[1] = p->KAP; dims[2] = p->KBP; dims[3] = p->LP; }
     } else if (w == "mhat" && p->T > 0) {
         *ptr = p->mhat; dims[0] = p->T; dims[1] = 2; dims[2] = p->KAP; dims[3] = p->KBP;
