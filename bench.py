@@ -38,6 +38,28 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def build_problem(cfg_name: str, **kw):
+    """The synthetic problems of BASELINE.json's configs (surfh_amd/synth.py).  Config 4 (12 sub-bands, 8000 planes) runs on the
+    reference driver's default 501 x 501 image (scripts/main_fusion.py:217): channel 4's field of view does not fit 251 pixels
+    (the reference raises, cython_2D_interpolation.py:472-478)."""
+    from surfh_amd import synth
+    if cfg_name == "2":
+        return synth.config2(**kw)
+    if cfg_name == "4":
+        return synth.config4(n_pix=501, **kw)
+    return synth.config3(**kw)
+
+
+WORKLOADS = {
+    "2": ("CG-iterations/sec (forward+adjoint) on 251x251x1024 cube", "config2: band 2A, 251x251x1024 cube, 4-point dither, T=4, mu_reg=5e3"),
+    "3": ("CG-iterations/sec (forward+adjoint) on 251x251x4000 cube",
+          "config3: 4 MRS bands 1C,2A,2B,2C, 251x251x4000 cube, 4-point dither, T=4, mu_reg=5e3"),
+    "4": ("CG-iterations/sec (forward+adjoint) on 501x501x8000 cube",
+          "config4: all 12 MRS sub-bands, 501x501x8000 cube (the reference driver's default image size; band 4 does not fit 251), "
+          "4-point dither, T=4, mu_reg=5e3"),
+}
+
+
 def cpu_baseline(cfg_name: str, budget_s: float):
     """The oracle (float64 NumPy/SciPy port of the reference chain) timed on the host cores on a
     bounded sample of the same workload: every `stride`-th cube plane, full detector axes,
@@ -45,8 +67,8 @@ def cpu_baseline(cfg_name: str, budget_s: float):
     full-size rate is sample_rate / stride."""
     from oracle import surfh_oracle as orc
     from surfh_amd import synth
-    stride = 16 if cfg_name == "2" else 32
-    prob = (synth.config2 if cfg_name == "2" else synth.config3)(lam_stride=stride)
+    stride = {"2": 16, "3": 32, "4": 128}[cfg_name]
+    prob = build_problem(cfg_name, lam_stride=stride)
     specs = [orc.ChannelSpec(i.fov.alpha_width, i.fov.beta_width, (0.0, 0.0), i.fov.angle, i.det_pix_size, i.n_slit,
                              i.w_blur.grating_resolution, i.wavel_axis, i.name) for i in prob["ifus"]]
     pts = [[(c.alpha, c.beta) for c in pl] for pl in prob["pointings"]]
@@ -75,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400, help="timed CG iterations (400 x 3 ms: the timed region is >= 1 s and holds the residual refreshes of qmm.lcg, one every 50 iterations)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="3", choices=["2", "3"])
+    ap.add_argument("--config", default="3", choices=["2", "3", "4"])
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-verify", action="store_true", help="skip the randn dot test on the float64-accumulating verification plan")
@@ -85,7 +107,7 @@ def main():
     if args.plan_only:
         from surfh_amd import synth
         from surfh_amd.fusion import plan_assignment
-        prob = (synth.config2 if args.config == "2" else synth.config3)(geometry_only=True)
+        prob = build_problem(args.config, geometry_only=True)
         asg, loads, imb = plan_assignment(prob, args.gpus)
         print(json.dumps({"config": args.config, "n_gpus": args.gpus, "assignment": repr(asg),
                           "predicted_us_per_iteration_per_rank": [round(v, 1) for v in loads], "imbalance": round(imb, 4),
@@ -117,7 +139,7 @@ def main():
     from surfh_amd import synth
     from surfh_amd.fusion import DistributedFusion
     t0 = time.time()
-    prob = synth.config2() if args.config == "2" else synth.config3()
+    prob = build_problem(args.config)
     log(f"[rank {rank}] problem built in {time.time() - t0:.1f}s")
     t0 = time.time()
     fus = DistributedFusion(prob, rank=rank, world=world, device=local)
@@ -227,11 +249,13 @@ def main():
                     return "gemm_f32_kernel<128, 128>"
                 return "gemm_nt_f16x2_cc_kernel"
             if name.startswith("specmix_"):       # interleaved spectra where the two-piece fp16 passes run (dft_h2.hip)
-                return name + ("_ilv_kernel" if any(k.startswith("dft_h2_") for k in prof_all) else "_kernel")
+                return name + ("_ilv_kernel" if any(k.startswith(("dft_h2_", "dft_ct_")) for k in prof_all) else "_kernel")
             if name.startswith("dft_h2_") and name.endswith("_adjmix"):
                 return "dft_h2_adjmix_kernel"      # the adjoint's last pass with the conj(OTF) product and the wavelength reduction fused in
             if name.startswith("dft_h2_"):
                 return "dft_h2_kernel"             # four template instances <KIND, MIX> of one kernel (dft_h2.hip)
+            if name.startswith("dft_ct_"):
+                return "dft_ct_kernel"             # template instances <R, loader, epilogue> of one kernel (dft_ct.hip)
             if name.startswith("dft_rx3_"):
                 return "dft_rx3_kernel"            # four template instances <KIND, MIX> of one kernel (dft_rx3.hip)
             if name.startswith("dft_fold_cols"):
@@ -286,20 +310,17 @@ def main():
                 # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
                 # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel
                 # (complex pass) and one of dft_fold_kernel (real pass): half of a transform's bytes per launch.
-                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith(("dft_fold", "dft_rx3", "dft_h2")) else None
+                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith(("dft_fold", "dft_rx3", "dft_h2", "dft_ct")) else None
                 ach = bytes_launch / avg_s / 1e9 if bytes_launch else None
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic, "kernel": dom,
                         "launches": cnt, "avg_ms": ms / cnt}
         out = {
-            "metric": "CG-iterations/sec (forward+adjoint) on 251x251x4000 cube" if args.config == "3"
-                      else "CG-iterations/sec (forward+adjoint) on 251x251x1024 cube",
+            "metric": WORKLOADS[args.config][0],
             "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": el / args.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32 (storage and accumulation; products as 2-piece fp16 splits -- 3 products per fp32 product, 1 on the far tails of the spectral response -- on the 16-bit matrix cores, in the spectral-blur GEMM and in the DFT passes)", "data": "synthetic",
-            "config": {"workload": ("config3: 4 MRS bands 1C,2A,2B,2C, 251x251x4000 cube, 4-point dither, T=4, mu_reg=5e3"
-                                    if args.config == "3" else
-                                    "config2: band 2A, 251x251x1024 cube, 4-point dither, T=4, mu_reg=5e3"),
+            "config": {"workload": WORKLOADS[args.config][1],
                        "parallelism": f"{world} rank(s), (band,pointings) units {fus.assignment}",
                        "osize_rank0": int(m.osize), "grad_norm_first_last": [fus.grad_norm[0], fus.grad_norm[-1]]},
             "roofline": roof, "parity_gates": gate, "stage_ms_per_step": stage_ms,
@@ -309,7 +330,7 @@ def main():
         # the HBM-bound half of the path as a whole: everything a step spends on its two 2-D transforms, the OTF product and
         # the wavelength reduction (the DFT passes, the fused adjoint tail or the separate reduction kernel) against the
         # algorithmic bytes of the FFT-conv stage.  Per-stage times of the warm-up steps (every stage bracketed).
-        stage_keys = ("dft_rx3", "dft_fold", "dft_h2", "specmix_adj", "specmix_fwd")
+        stage_keys = ("dft_rx3", "dft_fold", "dft_h2", "dft_ct", "specmix_adj", "specmix_fwd")
         dft = [(k, v) for k, v in groups_all.items() if k.startswith(stage_keys)]
         if dft:
             n_l = sum(v[0] for _, v in dft)

@@ -50,10 +50,12 @@ struct DftCtArgs {
     // optional list of super-tiles (128 columns, numbered batch-major) to transform, ascending
     const int *vlist = nullptr;
     int nvalid = 0;
-    // optional k-step limit per chunk of 128 columns (chunk = (first column of the tile % tabLP) / 128): the source rows of
-    // the sub-sequences beyond ktab[chunk] k-steps of 16 are zero or immaterial
-    const int *ktab = nullptr;
-    int tabLP = 0;
+    // optional limits per chunk of 2^tabShift columns (chunk = (first column of the tile % tabLP) >> tabShift; 7: 128 complex
+    // columns, 6: 64 packed pairs = 128 wavelengths):
+    //   ktab[chunk] = k-steps of 16 to run (>= 2): the elements of the sub-sequences beyond are zero or immaterial
+    //   rtab[chunk] = largest output row k, counted as min(k, N - k), that anybody reads: the rows beyond are not stored
+    const int *ktab = nullptr, *rtab = nullptr;
+    int tabLP = 0, tabShift = 7;
 };
 
 // device-resident constants of one transform length: the LDS image of the folded M-point (cos | sin) matrices as two

@@ -12,7 +12,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef CT_EXP
-#define CT_EXP 0        // tools/exp: 2 no stores, 4 no MFMAs, 8 no exchange (barriers stay)
+#define CT_EXP 0        // tools/exp: 2 no stores (and no combine: dead code), 4 no MFMAs, 16 no group synchronisation (wrong results), 32 no loads, 64 workgroup barrier instead of the group counters
 #endif
 
 namespace {
@@ -66,8 +66,24 @@ __device__ __forceinline__ float pair_swap(float x) {
 // workgroup barrier that waits for LDS traffic only: global loads of the next tile and stores of the previous phase stay in flight
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// The R waves of a group meet at a counter in LDS instead of the workgroup barrier, so the groups of a workgroup run
+// decoupled: one group's loads and MFMAs overlap the other's stores (0.67 -> 0.62 ms per 2 GB pass at N = 501).  Every wave
+// adds 1 per phase after its LDS writes (the LDS operations of a wave are performed in order) and waits until the count
+// reaches R x phases.
+__device__ __forceinline__ void group_arrive_wait(unsigned *cnt, unsigned target, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    while (true) {
+        const unsigned v = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if ((int)(v - target) >= 0) break;
+        __builtin_amdgcn_s_sleep(1);
+    }
+    asm volatile("" ::: "memory");
+}
+
 template <int R, int LD, int EP>
 __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const uint4 *__restrict__ img, const float *__restrict__ twg,
+                                                            const int *__restrict__ vl, const int *__restrict__ ktab, const int *__restrict__ rtab,
                                                             int MT, int KT, int kA, int NU) {
     constexpr int NG = Cfg<R>::NG, NW = Cfg<R>::NW, NTH = Cfg<R>::NTH, UPS = Cfg<R>::UPS;
     extern __shared__ __attribute__((aligned(16))) unsigned short lds[];
@@ -88,17 +104,18 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
     const unsigned c4 = (unsigned)l31 * (LD == DFT_CT_HPACK ? 8u : 4u);
     float *const xbuf = reinterpret_cast<float *>(lds + IMGH);
     float *const twl = xbuf + 2 * NW * XFLOATS;                // [M][R - 1] (cos, sin)
-    float4 *const mixbuf = reinterpret_cast<float4 *>(twl + (((M * (R - 1) * 2) + 3) & ~3));
+    unsigned *const gsync = reinterpret_cast<unsigned *>(twl + (((M * (R - 1) * 2) + 3) & ~3));      // one arrival counter per group
+    float4 *const mixbuf = reinterpret_cast<float4 *>(gsync + 4);
 
     {   // constants: global -> LDS, once
         uint4 *l4 = reinterpret_cast<uint4 *>(lds);
         for (int i = tid; i < IMGH / 8; i += NTH) l4[i] = img[i];
         for (int i = tid; i < M * (R - 1) * 2; i += NTH) twl[i] = twg[i];
+        if (tid < 4) gsync[tid] = 0u;
     }
     // this workgroup's contiguous range of units (NG adjacent tiles of 16 columns, one per group of waves)
     const int u0 = (int)((long)NU * blockIdx.x / gridDim.x), u1 = (int)((long)NU * (blockIdx.x + 1) / gridDim.x);
     const int ntw = u1 - u0;
-    const int *vl = g.vlist;
 #define CT_TILE(vu_) ((vl ? vl[(vu_) / UPS] * UPS + (vu_) % UPS : (vu_)) * NG + grp)
 
     // fused spectral mix: column (k, kb) of mhat for all N rows k as [k][template pair](re, im, re, im), two tables in turn
@@ -142,8 +159,8 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
     // limit on rows x pitch), the row inside the step as a scalar byte offset, the lane part in one VGPR.
     const float *tp = g.src;           // first row of this wave's sub-sequence in the current tile (HPACK: row 0 of the tile)
 #define CT_RSRC(ptr_) __builtin_amdgcn_make_buffer_rsrc((void *)(ptr_), 0, 0xFFFFFFFF, 0x00020000)
-#define CT_BLOAD(r_, v_, s_) __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_, (int)(v_), (int)(s_), 0))
-#define CT_BLOAD2(r_, v_, s_) __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_, (int)(v_), (int)(s_), 0))
+#define CT_BLOAD(r_, v_, s_) ((CT_EXP & 32) ? __uint_as_float((v_) + (s_)) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_, (int)(v_), (int)(s_), 0)))
+#define CT_BLOAD2(r_, v_, s_) ((CT_EXP & 32) ? f32x2{__uint_as_float((v_) + (s_)), 1.f} : __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_, (int)(v_), (int)(s_), 0)))
 #define CT_LSETUP(t_)                                                                                           \
     {                                                                                                           \
         const int tx = (t_) % tilesX;                                                                           \
@@ -304,8 +321,9 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
             for (int r = 0; r < 16; ++r) acc1[i][r] = acc2[i][r] = 0.f;
         const bool more = vu + 1 < u1;
         const int next = more ? CT_TILE(vu + 1) : tile;
-        const int chunk_ = g.tabLP ? (int)(((long)(tile % tilesX) * 16 % g.tabLP) >> 7) : 0;
-        const int nkt = g.ktab ? g.ktab[chunk_] : KT;
+        const int chunk_ = g.tabLP ? (int)(((long)(tile % tilesX) * 16 % g.tabLP) >> g.tabShift) : 0;
+        const int nkt = ktab ? ktab[chunk_] : KT;
+        const int rlim = rtab ? rtab[chunk_] : N;          // output rows k with min(k, N - k) beyond it are not stored
         for (int kt = 0; kt + 1 < nkt; ++kt) {
             CT_MFMA(0, kt, acc1, c0h, c0l);
             CT_FOLD(kt + 1);
@@ -377,7 +395,8 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
                         xw[slot * 32] = f * a1 + fq * a2;
                         xw[(16 + slot) * 32] = f * a1 - fq * a2;
                     }
-                    lds_barrier();
+                    if (CT_EXP & 64) lds_barrier();
+                    else if (!(CT_EXP & 16)) group_arrive_wait(gsync + grp, (unsigned)(R * phase), lane);
                     const float *const xg = xbuf + (buf * NW + grp * R) * XFLOATS + l31 + 32 * he;
 #pragma unroll
                     for (int xi_ = 0; xi_ < (8 + R - 1) / R; ++xi_) {
@@ -428,8 +447,10 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
                                     if (!(CT_EXP & 2)) {
                                         const __amdgpu_buffer_rsrc_t wp_ = CT_RSRC(dtile + (long)(r0 + M * k1) * ldc_o);
                                         const __amdgpu_buffer_rsrc_t wm_ = CT_RSRC(dtile + (long)(M - r0 - 1 + M * k1) * ldc_o);
-                                        if (okr) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xp[k1]), wp_, (int)vlo, 0, 0);
-                                        if (okm) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xm[k1]), wm_, (int)vmi, 0, 0);
+                                        const int kp_ = r + M * k1, km_ = rm + M * k1;
+                                        const int fp_ = kp_ < N - kp_ ? kp_ : N - kp_, fm_ = km_ < N - km_ ? km_ : N - km_;
+                                        if (okr && fp_ <= rlim) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xp[k1]), wp_, (int)vlo, 0, 0);
+                                        if (okm && fm_ <= rlim) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xm[k1]), wm_, (int)vmi, 0, 0);
                                     }
                                 }
                             } else {
@@ -447,7 +468,7 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
                                     const float v1 = ((var != 0) != cjg) ? -ds : ds;
                                     const bool st = okr && (okm || kp <= kq);
                                     const int row = cjg ? kq : kp;
-                                    if (st && !(CT_EXP & 2)) {
+                                    if (st && row <= rlim && !(CT_EXP & 2)) {
                                         const f32x2 v2 = {s, v1};
                                         *reinterpret_cast<f32x2 *>(dtile + (long)row * ldc_o + 2 * l31) = v2;
                                     }
@@ -483,7 +504,7 @@ size_t ct_lds_bytes(int R, int M, int MT, int KT, bool mix) {
     const int NW = (R == 2 ? 4 : 2) * R;
     size_t b = (size_t)4 * KT * (32 * MT * 16) * 2;                        // image
     b += (size_t)2 * NW * XFLOATS * 4;                                    // exchange buffers
-    b += (size_t)(((M * (R - 1) * 2) + 3) & ~3) * 4;                      // twiddles
+    b += (size_t)(((M * (R - 1) * 2) + 3) & ~3) * 4 + 16;                 // twiddles, group counters
     if (mix) b += (size_t)2 * (R * M) * 2 * sizeof(float4);               // two mix tables
     return b;
 }
@@ -496,7 +517,7 @@ int launch_inst(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl, int
     if (int e = ensure_dynamic_lds(dft_ct_kernel<R, LD, EP>, ldsb, done)) return e;
     const dim3 grid((unsigned)(NU < cus ? NU : cus));
     hipLaunchKernelGGL((dft_ct_kernel<R, LD, EP>), grid, dim3(Cfg<R>::NTH), ldsb, stream, g, reinterpret_cast<const uint4 *>(pl.img), pl.tw,
-                       pl.MT, pl.KT, pl.kA, NU);
+                       g.vlist, g.ktab, g.rtab, pl.MT, pl.KT, pl.kA, NU);
     return (int)hipGetLastError();
 }
 
@@ -585,7 +606,7 @@ int launch_dft_ct(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl) {
     // 32-bit offsets inside a k-step: 16 rows of a sub-sequence; HPACK's edge steps address rows 0 .. N / 2 from the tile's first row
     if (16.0 * (double)g.R * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
     if (g.loader == DFT_CT_HPACK && ((double)(pl.N / 2) + 1.0) * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;
-    if (g.ktab && (g.tabLP < 128 || g.tabLP % 128)) return (int)hipErrorInvalidValue;
+    if ((g.ktab || g.rtab) && (g.tabLP < (1 << g.tabShift) || g.tabLP % (1 << g.tabShift) || g.tabShift < 4 || g.tabShift > 7)) return (int)hipErrorInvalidValue;
     static int cus_of[64] = {0};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return (int)hipErrorInvalidDevice;

@@ -15,8 +15,21 @@ constexpr int SURFH_MAX_TEMPLATES = 8;
 // transforms run in dft_h2.hip)
 int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, const float *tpl, float *spec,
                        int T, long PL, int LP, int ilv = 0);
+// options of the interleaved adjoint reduction (T > 0): `lim` = [2][LP / 128] per chunk of 128 wavelengths the largest k_beta and the
+// largest folded k_alpha inside the OTF's support (bins beyond were not written to `spec` and are skipped);  Nb != 0: the output is
+// the solver's Parseval-scaled half spectrum (bins that are their own conjugate x out_self, the others x out_pair) with
+// prior_mu * |D|^2 * prior_src added (surfh_normal_spec_dev; same arithmetic as the fused tail's reduction, dft_h2.h)
+struct SpecmixAdjOpt {
+    const int *lim = nullptr;
+    int Na = 0;
+    long KBP = 0;
+    int Nb = 0;
+    float out_self = 1.f, out_pair = 1.f;
+    const float *prior_src = nullptr;
+    float prior_mu = 0.f;
+};
 int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj,
-                       int T, long PL, int LP, bool f64 = false, int ilv = 0);
+                       int T, long PL, int LP, bool f64 = false, int ilv = 0, const SpecmixAdjOpt *opt = nullptr);
 
 // hth[(t,t')][k] = sum_l tpl[t,l] tpl[t',l] |sotf[k][l]|^2   (mixing.py:177-203), full T x T stored
 int launch_wct_hessian(hipStream_t s, const float *sotf, const float *tpl, float *hth, int T, long PL, int LP, int ilv = 0);

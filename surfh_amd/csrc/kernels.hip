@@ -158,19 +158,27 @@ __global__ __launch_bounds__(TPB) void specmix_fwd_ilv_kernel(const float *__res
 template <typename ACC>
 __global__ __launch_bounds__(TPB) void specmix_adj_ilv_kernel(const float *__restrict__ spec, const float *__restrict__ sotf,
                                                               const float *__restrict__ tpl, float *__restrict__ madj,
-                                                              int T, long PL, int LP) {
+                                                              int T, long PL, int LP, SpecmixAdjOpt o) {
     const long k = blockIdx.x;
     ACC ar[MAXT], ai[MAXT];
 #pragma unroll
     for (int t = 0; t < MAXT; ++t) ar[t] = ai[t] = (ACC)0;
     const float *hk = sotf + k * LP * 2, *yk = spec + k * LP * 2;
+    // support of the OTF (plan.hip otf_support): chunk c of 128 wavelengths holds nothing at k_beta > lim[c] or at a folded
+    // k_alpha > lim[LP / 128 + c]; `spec` was not written there
+    const int ka = o.KBP ? (int)(k / o.KBP) : 0, kb = o.KBP ? (int)(k % o.KBP) : 0;
+    const int af = ka < o.Na - ka ? ka : o.Na - ka, nch = LP >> 7;
     for (int l0 = threadIdx.x * 2; l0 < LP; l0 += TPB * 4) {      // two float4 of each array in flight per thread
         const int l1 = l0 + TPB * 2;
-        const bool two = l1 < LP;
-        const float4 ha = *reinterpret_cast<const float4 *>(hk + (long)l0 * 2);
-        const float4 ya = *reinterpret_cast<const float4 *>(yk + (long)l0 * 2);
-        const float4 hb = two ? *reinterpret_cast<const float4 *>(hk + (long)l1 * 2) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float4 yb = two ? *reinterpret_cast<const float4 *>(yk + (long)l1 * 2) : make_float4(0.f, 0.f, 0.f, 0.f);
+        // outside the support the loads are redirected to the bin's first wavelengths (cached lines, finite values) and weighted
+        // by zero: no branch around a load, no traffic for the skipped chunk
+        const bool one = !o.lim || (kb <= o.lim[l0 >> 7] && af <= o.lim[nch + (l0 >> 7)]);
+        const bool two = l1 < LP && (!o.lim || (kb <= o.lim[l1 >> 7] && af <= o.lim[nch + (l1 >> 7)]));
+        const int e0 = one ? l0 : (int)threadIdx.x % 64 * 2, e1 = two ? l1 : (int)threadIdx.x % 64 * 2;
+        const float4 ha = *reinterpret_cast<const float4 *>(hk + (long)e0 * 2);
+        const float4 ya = *reinterpret_cast<const float4 *>(yk + (long)e0 * 2);
+        const float4 hb = *reinterpret_cast<const float4 *>(hk + (long)e1 * 2);
+        const float4 yb = *reinterpret_cast<const float4 *>(yk + (long)e1 * 2);
         const float pr0 = ha.x * ya.x + ha.y * ya.y, pi0 = ha.x * ya.y - ha.y * ya.x;
         const float pr1 = ha.z * ya.z + ha.w * ya.w, pi1 = ha.z * ya.w - ha.w * ya.z;
         const float pr2 = hb.x * yb.x + hb.y * yb.y, pi2 = hb.x * yb.y - hb.y * yb.x;
@@ -178,7 +186,7 @@ __global__ __launch_bounds__(TPB) void specmix_adj_ilv_kernel(const float *__res
 #pragma unroll
         for (int t = 0; t < MAXT; ++t)
             if (t < T) {
-                const float2 wa = *reinterpret_cast<const float2 *>(tpl + (long)t * LP + l0);
+                const float2 wa = one ? *reinterpret_cast<const float2 *>(tpl + (long)t * LP + l0) : make_float2(0.f, 0.f);
                 const float2 wb = two ? *reinterpret_cast<const float2 *>(tpl + (long)t * LP + l1) : make_float2(0.f, 0.f);
                 ar[t] += (ACC)wa.x * (ACC)pr0 + (ACC)wa.y * (ACC)pr1 + (ACC)wb.x * (ACC)pr2 + (ACC)wb.y * (ACC)pr3;
                 ai[t] += (ACC)wa.x * (ACC)pi0 + (ACC)wa.y * (ACC)pi1 + (ACC)wb.x * (ACC)pi2 + (ACC)wb.y * (ACC)pi3;
@@ -203,7 +211,14 @@ __global__ __launch_bounds__(TPB) void specmix_adj_ilv_kernel(const float *__res
         ACC s = (ACC)0;
         for (int w = 0; w < TPB / 64; ++w) s += red[w][threadIdx.x];
         const int t = threadIdx.x >> 1, c = threadIdx.x & 1;
-        madj[((long)t * 2 + c) * PL + k] = (float)s;
+        const long oo = ((long)t * 2 + c) * PL + k;
+        float v = (float)s;
+        if (o.Nb) {     // the solver's Parseval-scaled half spectrum, mu and the quadratic prior folded in (dft_h2.h DftH2AdjMix)
+            v *= (kb == 0 || 2 * kb == o.Nb) ? o.out_self : o.out_pair;
+            if (o.prior_src && ka < o.Na && 2 * kb <= o.Nb)
+                v += o.prior_mu * (4.f - 2.f * cospif(2.f * (float)kb / (float)o.Nb) - 2.f * cospif(2.f * (float)ka / (float)o.Na)) * o.prior_src[oo];
+        }
+        madj[oo] = v;
     }
 }
 
@@ -1068,14 +1083,16 @@ int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, cons
 }
 
 int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, const float *tpl, float *madj, int T,
-                       long PL, int LP, bool f64, int ilv) {
+                       long PL, int LP, bool f64, int ilv, const SpecmixAdjOpt *opt) {
     if (T > MAXT) return (int)hipErrorInvalidValue;
+    const SpecmixAdjOpt o = opt ? *opt : SpecmixAdjOpt();
+    if (opt && (!ilv || T == 0 || (o.lim && LP % 128) || ((o.lim || o.Nb) && (o.KBP < 1 || o.Na < 1)))) return (int)hipErrorInvalidValue;
     if (ilv) {
         if (T == 0) {
             dim3 grid((LP / 2 + TPB - 1) / TPB, (unsigned)PL);
             hipLaunchKernelGGL(specmix_adj_plane_ilv_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP);
-        } else if (f64) hipLaunchKernelGGL(specmix_adj_ilv_kernel<double>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
-        else hipLaunchKernelGGL(specmix_adj_ilv_kernel<float>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP);
+        } else if (f64) hipLaunchKernelGGL(specmix_adj_ilv_kernel<double>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP, o);
+        else hipLaunchKernelGGL(specmix_adj_ilv_kernel<float>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP, o);
         return (int)hipGetLastError();
     }
     if (T == 0) {

@@ -944,7 +944,7 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
 // adjoint stays the transpose of the forward.  Nothing is dropped when every tile has such an entry (SURFH_OTF_SUPPORT=0: off).
 int otf_support(surfh_plan *p, const surfh_config *cfg) {
     const bool on = [] { const char *e = getenv("SURFH_OTF_SUPPORT"); return !(e && e[0] == '0'); }();      // read at plan creation
-    if (!on || !cfg->sotf || !p->h2 || p->T < 1 || !p->fuse_mix || p->LP % 128) return 0;
+    if (!on || !cfg->sotf || !p->ilv || p->T < 1 || !p->fuse_mix || p->LP % 128) return 0;
     const int nkb = p->Nb / 2 + 1, nch = (int)(p->LP / 128);
     std::vector<int> bmax(nch, -1), amaxk(nch, -1);   // largest k_beta / folded k_alpha of the support over a chunk's planes (-1: none)
     std::vector<double> km(nkb), kam(p->Na);
@@ -983,8 +983,18 @@ int otf_support(surfh_plan *p, const surfh_config *cfg) {
     if (dev_upload(&p->otf_vlist, vlist) || dev_upload(&p->otf_kbstart, kbstart) || dev_alloc(&p->ycol_mix, nyc)) return 1;
     if (hipMemset(p->ycol_mix, 0, nyc * sizeof(float)) != hipSuccess) return fail("memset failed");
     p->otf_nvalid = (int)vlist.size();
-    std::vector<int> tabs((size_t)3 * nch);
+    std::vector<int> tabs((size_t)(p->ct ? 4 : 3) * nch);
     for (int j = 0; j < nch; ++j) {
+        if (p->ct) {
+            // sub-sequence n1 of a length R M: element j stands for the rows R j + n1 and N - (R j - n1); inside the support
+            // (folded index <= amax) for j <= (amax + R - 1) / R
+            const int ja = (std::max(amaxk[j], 0) + p->ctA.R - 1) / p->ctA.R, jb = (std::max(bmax[j], 0) + p->ctB.R - 1) / p->ctB.R;
+            tabs[j] = std::min(std::max(ja / 16 + 1, 2), p->ctA.KT);              // forward's complex pass: k-steps in k_alpha
+            tabs[nch + j] = std::min(std::max(jb / 16 + 1, 2), p->ctB.KT);        // forward's pass along beta: k-steps in k_beta
+            tabs[2 * nch + j] = bmax[j];                                           // adjoint's first pass: last row k_beta stored; reduction: k_beta limit
+            tabs[3 * nch + j] = amaxk[j];                                          // adjoint's complex pass: last folded row k_alpha stored; reduction: limit
+            continue;
+        }
         tabs[j] = std::min(std::max((amaxk[j] + 16) / 16, 2), p->KPa / 16);
         tabs[nch + j] = std::min(std::max((bmax[j] + 16) / 16, 2), p->KPb / 16);
         tabs[2 * nch + j] = bmax[j] + 1;
@@ -1079,7 +1089,8 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
 
 // ---- Cooley-Tukey passes (dft_ct.h): the same four passes for N = R * M, interleaved complex arrays ---------------
 // cube [NBP][NAP][LP] -> spec [KAP][KBP][LP][2]        (tmp ycol viewed as Z[KBP][NAP][LP][2])
-int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false) {
+// `lists`: the caller is the adjoint's tail, whose reduction reads the spectrum only inside the OTF's support
+int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false, bool lists = false) {
     const long LP = p->LP;
     const int hb = p->Nb / 2 + 1;
     const bool sub = acols && p->ycol_adj && p->a_hi > p->a_lo;
@@ -1091,6 +1102,9 @@ int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false
     g.src = src + (long)a0 * LP; g.ldb = p->NAP * LP;
     g.dst = yc + 2 * (long)a0 * LP; g.ldc = 2 * p->NAP * LP;
     g.ncols = (int)(na * LP / 2); g.batch = 1;
+    // the reduction reads no k_beta beyond the support of a wavelength chunk: those rows are not stored (chunks of 64 packed pairs)
+    const bool supp = lists && p->otf_vlist && p->ycol_mix && p->otf_tabs && p->T > 0;
+    if (supp) { g.rtab = p->otf_tabs + 2 * (LP / 128); g.tabLP = (int)(LP / 2); g.tabShift = 6; }
     {
         Prof pr(p, "dft_ct_rows_fwd");
         LAUNCH_OK(launch_dft_ct(p->stream, g, p->ctB));
@@ -1101,6 +1115,10 @@ int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false
     h.src = yc; h.ldb = 2 * LP; h.sB = 2 * p->NAP * LP;
     h.dst = dst; h.ldc = 2 * p->KBP * LP; h.sC = 2 * LP;
     h.ncols = (int)LP; h.batch = hb;
+    if (supp) {       // only the (k_beta, wavelength chunk) super-tiles and the rows k_alpha inside the OTF's support
+        h.vlist = p->otf_vlist; h.nvalid = p->otf_nvalid;
+        h.rtab = p->otf_tabs + 3 * (LP / 128); h.tabLP = (int)LP;
+    }
     {
         Prof pr(p, "dft_ct_cols_fwd");
         LAUNCH_OK(launch_dft_ct(p->stream, h, p->ctA));
@@ -1120,6 +1138,10 @@ int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     g.ncols = (int)(hb * LP); g.batch = 1;
     if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
     if (mix && p->spec_in) { g.mhat = p->spec_in; g.mhat_self = 1.f; g.mhat_pair = 0.70710678118654752f; g.mix_Nb = p->Nb; }
+    // the OTF's support: tiles outside it are neither computed nor stored -- their place in ycol_mix is zero for good
+    const bool supp = mix && p->otf_vlist && p->ycol_mix && p->otf_tabs;
+    float *const yc = supp ? p->ycol_mix : p->ycol;
+    if (supp) { g.vlist = p->otf_vlist; g.nvalid = p->otf_nvalid; g.dst = yc; g.ktab = p->otf_tabs; g.tabLP = (int)LP; }
     {
         Prof pr(p, mix ? "dft_ct_cols_inv_mix" : "dft_ct_cols_inv");
         LAUNCH_OK(launch_dft_ct(p->stream, g, p->ctA));
@@ -1129,9 +1151,10 @@ int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     DftCtArgs h;   // c2r along beta, batched over alpha: two neighbouring half spectra as one Hermitian-extended complex sequence
     h.R = p->ctB.R; h.M = p->ctB.M; h.loader = DFT_CT_HPACK; h.epi = DFT_CT_STORE; h.sgn = 1.f;
     h.scale = (float)(1.0 / std::sqrt((double)p->Nb));
-    h.src = p->ycol + (long)a0 * 2 * p->KBP * LP; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
+    h.src = yc + (long)a0 * 2 * p->KBP * LP; h.ldb = 2 * LP; h.sB = 2 * p->KBP * LP;
     h.dst = dst + (long)a0 * LP; h.ldc = p->NAP * LP; h.sC = LP;
     h.ncols = (int)(LP / 2); h.batch = na;
+    if (supp) { h.ktab = p->otf_tabs + LP / 128; h.tabLP = (int)(LP / 2); h.tabShift = 6; }      // k_beta beyond the support: zero in ycol_mix
     {
         Prof pr(p, "dft_ct_rows_inv");
         LAUNCH_OK(launch_dft_ct(p->stream, h, p->ctB));
@@ -1208,7 +1231,21 @@ int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, b
 // `acols`: the cube is zero outside the alpha range of the channels' tables (the adjoint's accumulator)
 int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
     if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->spec_out ? p->spec_out : p->mhat, acols);
-    if (p->ct && !p->dense_dft ? rfft2_lam_ct(p, cube, p->spec, acols) : rfft2_cube(p, cube, p->spec)) return 1;
+    if (p->ct && !p->dense_dft) {
+        if (rfft2_lam_ct(p, cube, p->spec, acols, true)) return 1;
+        SpecmixAdjOpt o;
+        o.Na = p->Na; o.KBP = p->KBP;
+        if (p->T > 0 && p->otf_vlist && p->ycol_mix && p->otf_tabs) o.lim = p->otf_tabs + 2 * (p->LP / 128);
+        if (p->spec_out) {      // the solver's scaled half spectrum, mu and the quadratic prior folded in
+            o.Nb = p->Nb; o.out_self = p->spec_mu; o.out_pair = p->spec_mu * 1.41421356237309505f;
+            o.prior_src = p->spec_prior_src; o.prior_mu = p->spec_prior_mu;
+        }
+        Prof pr(p, "specmix_adj");
+        LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->spec_out ? p->spec_out : p->mhat, p->T, p->PL, p->LP, false, 1,
+                                     p->T > 0 ? &o : nullptr));
+        return 0;
+    }
+    if (rfft2_cube(p, cube, p->spec)) return 1;
     Prof pr(p, "specmix_adj");
     LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->ilv));
     return 0;
@@ -1730,6 +1767,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             if (dft_ct_plan_create(p->Na, &p->ctA)) return bail(fail("dft_ct plan (n_alpha = %d) failed", p->Na));
             if (p->Nb == p->Na) p->ctB = p->ctA;
             else if (dft_ct_plan_create(p->Nb, &p->ctB)) return bail(fail("dft_ct plan (n_beta = %d) failed", p->Nb));
+            if (p->T >= 1 && p->T <= 4 && otf_support(p, cfg)) return bail(1);
         }
         const char *e5 = getenv("SURFH_DFT_RX3");
         p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
@@ -2099,8 +2137,8 @@ int surfh_prior_add_dev(surfh_plan *p, const float *d, float *q, double mu_reg) 
 namespace {
 int spec_check(surfh_plan *p) {
     if (!p) return fail("null plan");
-    if (!(p->adjmix_part && p->h2 && p->T > 0 && p->fuse_mix && !p->dense_dft && !p->verify))
-        return fail("spectral-domain calls need the fused transform passes (dft_h2 with the fused adjoint tail)");
+    if (!(((p->adjmix_part && p->h2) || p->ct) && p->T > 0 && p->T <= 4 && p->fuse_mix && !p->dense_dft && !p->verify))
+        return fail("spectral-domain calls need the fused transform passes (dft_h2 with the fused adjoint tail, or dft_ct)");
     HIP_OK(hipSetDevice(p->dev));
     return 0;
 }
@@ -2111,7 +2149,7 @@ struct SpecScope {      // the transient pointers never outlive a call
 }  // namespace
 
 int surfh_spec_supported(surfh_plan *p) {
-    return p && p->adjmix_part && p->h2 && p->T > 0 && p->fuse_mix && !p->dense_dft && !p->verify && p->prior_kind == 0;
+    return p && ((p->adjmix_part && p->h2) || p->ct) && p->T > 0 && p->T <= 4 && p->fuse_mix && !p->dense_dft && !p->verify && p->prior_kind == 0;
 }
 int64_t surfh_spec_size(surfh_plan *p) { return p ? (int64_t)2 * p->T * p->PL : 0; }
 

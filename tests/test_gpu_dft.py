@@ -145,12 +145,14 @@ def test_fused_adjoint_tail(shape, L, T, monkeypatch):
     assert e1 < TOL and e0 < TOL and d < TOL, (e1, e0, d)
 
 
-@pytest.mark.parametrize("shape,L,sig", [((251, 251), 300, (2.0, 4.5)), ((128, 200), 260, (3.0, 3.0)), ((251, 130), 140, (5.0, 2.5))])
+@pytest.mark.parametrize("shape,L,sig", [((251, 251), 300, (2.0, 4.5)), ((128, 200), 260, (3.0, 3.0)), ((251, 130), 140, (5.0, 2.5)),
+                                         ((501, 300), 260, (2.5, 6.0)), ((512, 512), 140, (7.0, 3.0))])
 def test_otf_support_lists(shape, L, sig):
     """Band-limited OTFs (clean Gaussians, widths changing along the wavelength axis): the forward's complex pass and the fused
     adjoint tail visit only the (k_beta, 128-wavelength chunk) super-tiles in which the OTF reaches 2^-24 of its plane's peak
     (plan.hip otf_support) -- chunks with different cutoffs, k_beta values without any tile, a cutoff that rises with the
-    wavelength.  Both directions against numpy float64, and the forward against the same plan with the lists off."""
+    wavelength.  Both directions against numpy float64.  The last two shapes run the Cooley-Tukey passes (dft_ct.hip), where the
+    lists also limit the rows the adjoint's passes store and the bins its reduction reads."""
     import ctypes
     from surfh_amd.mixing import Model_WCT
     from surfh_amd.synth import ir2fr
