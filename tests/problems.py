@@ -99,6 +99,31 @@ def two_channel_disjoint():
                 templates=tpl, sotf=sotf, pointings=[p1, p2], maps=maps, step_deg=STEP_DEG)
 
 
+def two_channel_mid():
+    """128x128x512: large enough for every fast path of the HIP operator to engage -- the fused adjoint tail (127 <= N <= 255),
+    four 128-wavelength chunks (OTF-support lists with chunk-dependent cutoffs), detector axes of 400 samples at the real
+    bands' sampling, long enough for the spectral response to have far tails inside a band in both directions (K-step classes
+    of the spectral-blur GEMMs), two channels (grouped adjoint
+    GEMMs), a field of view well inside the image (column range of the transforms) -- and small enough for the float64 oracle
+    to finish in seconds.  The PSF support is 81x81 so that the long-wavelength OTFs have a clean cutoff."""
+    N, Lc = 128, 512
+    ax = orc.synthetic_axes(N, STEP_DEG)
+    wav = np.linspace(7.40, 8.06, Lc)
+    s1 = orc.ChannelSpec(1.0 / 3600, 1.2 / 3600, (0.0, 0.0), 8.2, 0.196, 5, 3050.0, np.linspace(7.45, 7.95, 400), "A")
+    s2 = orc.ChannelSpec(1.1 / 3600, 1.0 / 3600, (0.0, 0.0), -5.0, 0.196, 4, 2900.0, np.linspace(7.52, 8.02, 390), "B")
+    tpl = orc.synthetic_templates(Lc)
+    yy, xx = np.mgrid[0:81, 0:81]
+    sig = np.linspace(2.0, 5.0, Lc)
+    psf = np.exp(-((yy - 40) ** 2 + (xx - 40) ** 2)[None] / (2.0 * sig[:, None, None] ** 2))
+    psf /= psf.sum(axis=(1, 2), keepdims=True)
+    sotf = orc.ir2fr(psf, (N, N))
+    p1 = orc.dither4(s1.det_pix_size, s1.beta_width / s1.n_slit)
+    p2 = orc.dither4(s2.det_pix_size, s2.beta_width / s2.n_slit)[:2]
+    maps = np.random.default_rng(9).random((4, N, N))
+    return dict(N=N, Lc=Lc, alpha_axis=ax, beta_axis=ax.copy(), wavel=wav, specs=[s1, s2],
+                templates=tpl, sotf=sotf, pointings=[p1, p2], maps=maps, step_deg=STEP_DEG)
+
+
 def oracle_model(cfg, box="fft", gridding="bilinear"):
     return orc.OracleModel(cfg["sotf"], cfg["templates"], cfg["alpha_axis"], cfg["beta_axis"],
                            cfg["wavel"], cfg["specs"], cfg["step_deg"], cfg["pointings"], box=box, gridding=gridding)

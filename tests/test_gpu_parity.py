@@ -489,16 +489,14 @@ def test_disjoint_wavelength_windows(lmm):
 @pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
                                  {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_H2": "0", "SURFH_DFT_PACKED": "0"}, {"SURFH_DFT_H2": "0"},
                                  {"SURFH_GATHER_SORTED": "0"}, {"SURFH_SCATTER_RMW_ALL": "1"}, {"SURFH_SCATTER_GROUPED": "0"},
-                                 {"SURFH_GATHER_GROUPED": "0"}, {"SURFH_ALPHA_RANGE": "0"}, {"SURFH_ADJ_FUSED": "0"}, {"SURFH_ADJ_CLEAR": "1"},
-                                 {"SURFH_WBLUR_FAR": "0"}, {"SURFH_WBLUR_PERM": "0"}, {"SURFH_OTF_SUPPORT": "0"}, {"SURFH_OTF_RANGES": "0"},
-                                 {"SURFH_GEMM_GROUPED": "0"}],
+                                 {"SURFH_GATHER_GROUPED": "0"}, {"SURFH_ADJ_CLEAR": "1"}],
                          ids=["fold_fp32", "dense_dft", "unfused_mix", "wblur_fp32", "two_streams", "dft_bf16_two_pass_complex",
                               "dft_bf16_three_piece", "gather_rows_unsorted", "scatter_rmw_everywhere", "scatter_row_by_row",
-                              "gather_row_by_row", "transform_whole_cube", "adjoint_tail_separate", "adjoint_clears_accumulator",
-                              "gemm_three_products_everywhere", "gemm_adjoint_plain_tiles", "whole_spectrum", "otf_support_lists_only",
-                              "adjoint_gemms_one_by_one"])
+                              "gather_row_by_row", "adjoint_clears_accumulator"])
 def test_alternative_kernel_paths(env):
-    """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green."""
+    """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green.  Only the switches that
+    change something at config 1 (64 x 64 x 128, one wavelength chunk) are listed here; the ones whose fast side needs N >= 127,
+    several wavelength chunks or a long detector axis are compared in test_alternative_kernel_paths_where_they_engage."""
     cfg = problems.config1()
     om = problems.oracle_model(cfg, box="direct")
     old = {k: os.environ.get(k) for k in env}
@@ -521,6 +519,85 @@ def test_alternative_kernel_paths(env):
         assert ey < TOL and ea < TOL
     finally:
         m.close()
+
+
+@pytest.fixture(scope="module")
+def mid():
+    """problems.two_channel_mid with the default plan's outputs and the float64 oracle's."""
+    cfg = problems.two_channel_mid()
+    om = problems.oracle_model(cfg, box="direct")
+    rng = np.random.default_rng(12)
+    u = rng.standard_normal(om.osize)
+    m = build_model(cfg)
+    try:
+        state = dict(ksteps=[int(v) for v in m.debug_buffer("ksteps")], otf=[int(v) for v in m.debug_buffer("otf")[:2]],
+                     rng=[int(v) for v in m.debug_buffer("range")], spec=bool(m.spec_supported()))
+        out = dict(fwd=np.asarray(m.forward(cfg["maps"])), adj=np.asarray(m.adjoint(u)))
+        # zero-mean maps: sign-cancelling sums with the far K steps on one fp16 product and the OTF's support lists on
+        xr = rng.standard_normal(om.ishape)
+        state["fwd_randn"] = rel(m.forward(xr), om.forward(xr))
+    finally:
+        m.close()
+    ref = dict(fwd=om.forward(cfg["maps"]), adj=om.adjoint(u))
+    return cfg, u, out, ref, state
+
+
+def test_default_paths_engage_at_mid_size(mid):
+    """Every fast path is really in use on the problem the A/B cases below compare on (at config 1 none of them is: one
+    wavelength chunk, N = 64, a detector axis of 48 samples)."""
+    cfg, u, out, ref, st = mid
+    N = cfg["N"]
+    print("mid-size plan:", st)
+    assert st["ksteps"][1] > 0 and st["ksteps"][3] > 0                     # far K steps in both spectral-blur GEMMs
+    assert 0 < st["otf"][0] < st["otf"][1]                                 # some, not all, super-tiles inside the OTF's support
+    assert st["rng"][0] > 0 and st["rng"][1] < N                           # cube columns no channel sees
+    assert st["spec"]                                                      # fused adjoint tail (spectral-domain solver calls)
+    assert rel(out["fwd"], ref["fwd"]) < TOL and rel(out["adj"], ref["adj"]) < TOL      # adjoint: zero-mean data
+    assert st["fwd_randn"] < TOL, st["fwd_randn"]
+
+
+@pytest.mark.parametrize("env,changes_bits", [({"SURFH_WBLUR_FAR": "0"}, True), ({"SURFH_WBLUR_PERM": "0"}, True),
+                                              ({"SURFH_OTF_SUPPORT": "0"}, True), ({"SURFH_OTF_RANGES": "0"}, False),
+                                              ({"SURFH_ADJ_FUSED": "0"}, True), ({"SURFH_ALPHA_RANGE": "0"}, False),
+                                              ({"SURFH_GEMM_GROUPED": "0"}, False), ({"SURFH_DFT_H2": "0"}, True)],
+                         ids=["gemm_three_products_everywhere", "gemm_adjoint_plain_tiles", "whole_spectrum", "otf_support_lists_only",
+                              "adjoint_tail_separate", "transform_whole_cube", "adjoint_gemms_one_by_one", "dft_bf16_three_piece"])
+def test_alternative_kernel_paths_where_they_engage(mid, env, changes_bits):
+    """A/B of the switches whose fast side needs a problem of some size (tests/problems.py two_channel_mid): both sides within
+    1e-5 of the float64 oracle; where the two sides run different arithmetic the outputs must differ in their bits (the switch
+    did something), where the fast side only skips exact zeros or regroups launches they must not."""
+    cfg, u, out, ref, st = mid
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        m = build_model(cfg)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k)
+            else:
+                os.environ[k] = v
+    try:
+        ks = [int(v) for v in m.debug_buffer("ksteps")]
+        otf = [int(v) for v in m.debug_buffer("otf")[:2]]
+        rg = [int(v) for v in m.debug_buffer("range")]
+        y, a = np.asarray(m.forward(cfg["maps"])), np.asarray(m.adjoint(u))
+    finally:
+        m.close()
+    ey, ea = rel(y, ref["fwd"]), rel(a, ref["adj"])
+    same = bool(np.array_equal(y, out["fwd"]) and np.array_equal(a, out["adj"]))
+    note("alt_path_mid", env=json.dumps(env), fwd=ey, adj=ea, same_bits=same)
+    print(f"{env}: forward {ey:.2e} adjoint {ea:.2e}, same bits as the default plan: {same}; ksteps {ks} otf {otf} range {rg}")
+    assert ey < TOL and ea < TOL
+    assert same != changes_bits, (env, same)
+    if "SURFH_WBLUR_FAR" in env:
+        assert ks[1] == 0 and ks[3] == 0
+    if "SURFH_WBLUR_PERM" in env:
+        assert ks[2:] != st["ksteps"][2:]
+    if "SURFH_OTF_SUPPORT" in env:
+        assert otf[0] == 0 or otf[0] == otf[1]
+    if "SURFH_ALPHA_RANGE" in env:
+        assert rg[0] == 0 and rg[1] == cfg["N"]
 
 
 @pytest.mark.parametrize("maker", [problems.config1, problems.two_channel_small, problems.two_channel_disjoint],
