@@ -108,10 +108,12 @@ def main():
         from surfh_amd import synth
         from surfh_amd.fusion import plan_assignment
         prob = build_problem(args.config, geometry_only=True)
-        asg, loads, imb = plan_assignment(prob, args.gpus)
+        asg, loads, imb, times = plan_assignment(prob, args.gpus, with_times=True)
         print(json.dumps({"config": args.config, "n_gpus": args.gpus, "assignment": repr(asg),
-                          "predicted_us_per_iteration_per_rank": [round(v, 1) for v in loads], "imbalance": round(imb, 4),
-                          "gate": 0.15, "ok": bool(imb <= 0.15)}))
+                          "predicted_compute_us_per_iteration_per_rank": [round(v, 1) for v in loads], "compute_imbalance": round(imb, 4),
+                          "predicted_us_with_group_allreduces_per_rank": [round(v, 1) for v in times],
+                          "note": "chosen by the predicted time of the slowest rank, group-local all-reduces of split bands included "
+                                  "(SURFH_PARTITION=balanced: compute-only rule, imbalance gate 15 %); link model unmeasured"}))
         return
 
     import torch
@@ -284,9 +286,10 @@ def main():
         groups_all = grouped(prof_all)         # warm-up steps: every stage
         roof = None
         stage_ms = {k: round(v[1] / max(n_all, 1), 4) for k, v in sorted(groups_all.items(), key=lambda kv: -kv[1][1])}
-        traffic_file = os.path.join(ROOT, "profiles", f"r02_pmc_traffic_config{args.config}.json")
-        if not os.path.exists(traffic_file):
-            traffic_file = os.path.join(ROOT, "profiles", f"r01_final_pmc_traffic_config{args.config}.json")
+        traffic_file = os.path.join(ROOT, "profiles", f"r03_pmc_traffic_config{args.config}.json")
+        for alt in (f"r02_pmc_traffic_config{args.config}.json", f"r01_final_pmc_traffic_config{args.config}.json"):
+            if not os.path.exists(traffic_file):
+                traffic_file = os.path.join(ROOT, "profiles", alt)
         pmc = json.load(open(traffic_file)) if os.path.exists(traffic_file) else {}
         if groups:
             dom = max(groups, key=lambda k: groups[k][1])
@@ -315,6 +318,10 @@ def main():
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic, "kernel": dom,
                         "launches": cnt, "avg_ms": ms / cnt}
+            if roof is not None:
+                # `traffic` is not measured in this run: PMC counters need their own rocprofv3 passes (tools/pmc_traffic.py)
+                roof["traffic_source"] = os.path.relpath(traffic_file, ROOT) if traffic is not None else None
+        refreshes = sum(1 for i in range(args.warmup, args.warmup + args.steps) if i % 50 == 0)
         out = {
             "metric": WORKLOADS[args.config][0],
             "value": args.steps / el, "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -323,6 +330,7 @@ def main():
             "config": {"workload": WORKLOADS[args.config][1],
                        "parallelism": f"{world} rank(s), (band,pointings) units {fus.assignment}",
                        "osize_rank0": int(m.osize), "grad_norm_first_last": [fus.grad_norm[0], fus.grad_norm[-1]]},
+            "refreshes_in_timed_region": refreshes,
             "roofline": roof, "parity_gates": gate, "stage_ms_per_step": stage_ms,
             "stage_ms_note": f"per-stage HIP-event times from the {n_all} untimed warm-up step(s) with every stage bracketed; "
                              "the timed region brackets only the kernel group of `roofline`",
@@ -364,6 +372,28 @@ def main():
                                                           "the spectral response's diagonal, one on its far tails) against the dense fp16 / bf16 MFMA peak",
                                                   "k_steps_near_far_forward_adjoint": [int(v) for v in ks],
                                                   "traffic": pmc.get(gm[0][0], {}).get("hbm_bytes_per_launch")}
+        if world == 1:
+            # The exported solver -- surfh_cg, what QuadCriterion_MRS.run_method('lcg') and INTEGRATION.md's qmm.lcg replacement
+            # run (fusion_CT.py:194-225) -- outside the timed region: two calls of different length from host buffers; the
+            # difference of their wall times over the difference of their iteration counts leaves out the setup they share
+            # (copy of y to the device, b = mu A^T y, copy of x back).  tol = 0: no early stop.
+            try:
+                yh = y.cpu().numpy()
+                n1, n2 = 20, 20 + max(50, min(args.steps, 400))
+                ts = []
+                for nn in (n1, n2, n1, n2):
+                    t0c = time.perf_counter()
+                    _, gnc, nitc = m.cg(yh, mu=mu, mu_reg=mu_reg, max_iter=nn, tol=0.0)
+                    ts.append(time.perf_counter() - t0c)
+                    assert nitc == nn
+                dt = min(ts[1], ts[3]) - min(ts[0], ts[2])
+                out["surfh_cg_it_s"] = (n2 - n1) / dt
+                out["surfh_cg_note"] = (f"C-ABI surfh_cg (host buffers in and out) with max_iter {n1} and {n2}: ({n2} - {n1}) iterations / "
+                                        f"({min(ts[1], ts[3]):.3f} s - {min(ts[0], ts[2]):.3f} s); ratio to `value`: {(n2 - n1) / dt / (args.steps / el):.3f}")
+                log(f"[surfh_cg] {out['surfh_cg_it_s']:.1f} it/s through the C-ABI solver ({out['surfh_cg_note']})")
+            except Exception as e:
+                out["surfh_cg_it_s"] = None
+                out["surfh_cg_note"] = repr(e)
         if world == 1 and args.cpu_seconds > 0:
             try:
                 out["cpu_baseline"] = cpu_baseline(args.config, args.cpu_seconds)

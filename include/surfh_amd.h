@@ -136,7 +136,11 @@ int surfh_wct_expsol(surfh_plan *plan, const float *cube, const double *mu_reg, 
 
 /* ---- regularised least squares by linear CG (fusion_CT.py:118-238 + qmm.lcg) ----
  * minimises  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2).
- * grad_norm receives r.r (max_iter+1 doubles), nit the iterations done.             */
+ * grad_norm receives r.r (max_iter+1 doubles), nit the iterations done.
+ * Where the plan offers the spectral-domain calls (surfh_spec_supported) the loop keeps its vectors as the maps' scaled half
+ * spectra and its scalars on the device, and reads the trace -- qmm.lcg's stopping test sqrt(r.r) < size * tol -- every 8
+ * iterations only: it may run up to 7 iterations past the one that met the tolerance (x and nit are those of the last
+ * iteration run).  With a callback (surfh_cg_cb) the test is made after every iteration, as in qmm.lcg.             */
 int surfh_cg(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0,
              int32_t max_iter, double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
 /* The same solver with the per-iteration callback of qmm.lcg (`callback=` at fusion_CT.py:194-225): after

@@ -1499,8 +1499,10 @@ int ensure_hessian(surfh_plan *p) {
 
 int ensure_cg(surfh_plan *p) {
     if (p->cg_x) return 0;
+    // room for the vectors in either basis: the maps [T][Na][Nb] or their scaled half spectra [T][2][KAP][KBP]
+    const size_t n = std::max((size_t)p->isize, (size_t)2 * std::max(p->T, 0) * (size_t)p->PL);
     for (float **v : {&p->cg_x, &p->cg_r, &p->cg_d, &p->cg_q, &p->cg_b})
-        if (dev_alloc(v, (size_t)p->isize)) return 1;
+        if (dev_alloc(v, n)) return 1;
     return 0;
 }
 
@@ -2315,14 +2317,75 @@ int surfh_residual_dev(surfh_plan *p, float *r, const float *b, const float *q, 
 }
 
 // ---- full CG on one GPU (qmm.lcg semantics, see oracle/surfh_oracle.py:lcg) -------------------
+namespace {
+// The loop bench.py times, behind the exported solver: vectors = the maps' Parseval-scaled half spectra (surfh_normal_spec_dev:
+// no transform of the maps, no padding, no prior kernel inside an iteration), every scalar on the device
+// (surfh_cg_iter_nosync_dev), and the host reads the r.r trace -- the stopping test of qmm.lcg -- only every CG_CHECK iterations:
+// the loop may run up to CG_CHECK - 1 iterations past the one that met the tolerance (nit and x are those of the last iteration
+// run, grad_norm holds every r.r).  With a callback installed the trace and the iterate go to the host after every iteration,
+// as the callback's contract says.
+constexpr int CG_CHECK = 8;
+int cg_spectral(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol, int32_t refresh,
+                float *x, double *grad_norm, int32_t *nit, surfh_cg_callback callback, void *user) {
+    std::vector<float> hx;
+    if (callback) hx.resize((size_t)p->isize);
+    hipStream_t s = p->stream;
+    const long n = p->isize, nv = 2L * p->T * p->PL;
+    HIP_OK(hipMemcpyAsync(p->io_y, y, p->osize * sizeof(float), hipMemcpyHostToDevice, s));
+    if (surfh_adjoint_spec_dev(p, p->io_y, p->cg_b, mu, nullptr, 0.0)) return 1;           // b = mu A^T y
+    if (x0) {
+        HIP_OK(hipMemcpyAsync(p->io_x, x0, n * sizeof(float), hipMemcpyHostToDevice, s));
+        if (surfh_to_spec_dev(p, p->io_x, p->cg_x) || surfh_normal_spec_dev(p, p->cg_x, p->cg_q, mu, mu_reg)) return 1;
+        LAUNCH_OK(launch_residual(s, p->cg_r, p->cg_b, p->cg_q, nv));
+    } else {                                                                                // r = b - Q 0
+        LAUNCH_OK(launch_fill_zero(s, p->cg_x, nv));
+        HIP_OK(hipMemcpyAsync(p->cg_r, p->cg_b, nv * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
+    HIP_OK(hipMemcpyAsync(p->cg_d, p->cg_r, nv * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (surfh_cg_begin_dev(p, p->cg_r, nv)) return 1;
+    *nit = 0;
+    for (int it = 0; it < max_iter; ++it) {
+        if (surfh_normal_spec_dev(p, p->cg_d, p->cg_q, mu, mu_reg)) return 1;
+        if (refresh > 0 && it % refresh == 0) {             // residual recomputed from scratch
+            if (surfh_cg_xupdate_nosync_dev(p, p->cg_x, p->cg_d, p->cg_q, nv) || surfh_normal_spec_dev(p, p->cg_x, p->cg_q, mu, mu_reg) ||
+                surfh_cg_refresh_nosync_dev(p, p->cg_r, p->cg_b, p->cg_q, p->cg_d, nv))
+                return 1;
+        } else if (surfh_cg_iter_nosync_dev(p, p->cg_x, p->cg_r, p->cg_d, p->cg_q, nv)) {
+            return 1;
+        }
+        *nit = it + 1;
+        if (!callback && (it + 1) % CG_CHECK != 0 && it + 1 != max_iter) continue;
+        if (surfh_cg_trace(p, grad_norm, it + 2) != it + 2) return fail("CG trace read failed");     // synchronises
+        if (callback) {
+            if (surfh_from_spec_dev(p, p->cg_x, p->io_x)) return 1;
+            HIP_OK(hipMemcpyAsync(hx.data(), p->io_x, n * sizeof(float), hipMemcpyDeviceToHost, s));
+            HIP_OK(hipStreamSynchronize(s));
+            if (callback(user, it + 1, grad_norm, hx.data())) break;
+            HIP_OK(hipSetDevice(p->dev));
+        }
+        if (std::sqrt(grad_norm[it + 1]) < (double)n * tol) break;
+    }
+    if (surfh_cg_trace(p, grad_norm, *nit + 1) != *nit + 1) return fail("CG trace read failed");
+    if (surfh_from_spec_dev(p, p->cg_x, p->io_x)) return 1;
+    HIP_OK(hipMemcpyAsync(x, p->io_x, n * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIP_OK(hipStreamSynchronize(s));
+    return 0;
+}
+}  // namespace
+
 int surfh_cg_cb(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
                 int32_t refresh, float *x, double *grad_norm, int32_t *nit, surfh_cg_callback callback, void *user) {
     if (!p || !y || !x || !grad_norm || !nit) return fail("null argument");
-    std::vector<float> hx;             // host copy of the iterate handed to the callback
-    if (callback) hx.resize((size_t)p->isize);
     if (p->T <= 0) return fail("surfh_cg needs templates (the priors act on abundance maps)");
     HIP_OK(hipSetDevice(p->dev));
     if (ensure_cg(p)) return 1;
+    {   // SURFH_SPECTRAL_CG=0: vectors are the maps (the loop below)
+        const char *e = getenv("SURFH_SPECTRAL_CG");
+        if (!(e && e[0] == '0') && surfh_spec_supported(p) && max_iter < (1 << 16) - 1)
+            return cg_spectral(p, y, mu, mu_reg, x0, max_iter, tol, refresh, x, grad_norm, nit, callback, user);
+    }
+    std::vector<float> hx;             // host copy of the iterate handed to the callback
+    if (callback) hx.resize((size_t)p->isize);
     hipStream_t s = p->stream;
     const long n = p->isize;
     double *rr = p->dscal + 0, *dq = p->dscal + 1, *rrn = p->dscal + 2;

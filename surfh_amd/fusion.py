@@ -221,40 +221,47 @@ def unit_share(lins, k, u) -> float:
     return 1.0 if u == (0, 1) else ((u[2] - u[1]) / lins[k] if len(u) == 3 else 1.0 / u[1])
 
 
+def assignment_times(costs, lins, ybytes, asg):
+    """(per-rank compute loads, per-rank predicted times with the group-local all-reduces of shared bands) of an assignment, us."""
+    members = {}
+    for r, units in enumerate(asg):
+        for k, u in units:
+            members.setdefault(k, set()).add(r)
+    loads, times = [], []
+    for r, units in enumerate(asg):
+        load = sum(costs[k] * unit_share(lins, k, u) for k, u in units)
+        comm = 0.0
+        for k in {k for k, _ in units}:
+            m = len(members[k])
+            if m > 1:
+                comm += 20.0 + 2.0 * (m - 1) / m * ybytes[k] / 50e3
+        loads.append(load)
+        times.append(load + comm)
+    return loads, times
+
+
 def choose_lambda_assignment(costs, lins, ybytes, world):
     """Whole bands / equal parts of a band (``partition_lambda``) or equal-cost contiguous chunks (``partition_balanced``)?
-    Default (predicted per-rank cost within 15 %): whole bands / equal parts when that is already balanced to 5 %,
-    else the contiguous chunks.  ``SURFH_PARTITION=comm``: whichever has the smaller predicted time of its slowest rank with the
-    group-local all-reduces counted -- for every band a rank shares with others, 20 us + 2 (m - 1) / m * bytes of that band's
-    partial outputs at 50 GB/s (one xGMI link per pair).  The contiguous chunks put most ranks into TWO such groups: by this
-    model config 3 on 8 ranks takes 721 us per iteration with them and 655 us with two equal parts per band (compute 377 vs
-    up to 465 us) -- unmeasured, so not the default.  Returns (assignment, per-rank compute loads, per-rank predicted time)."""
+    Default: whichever has the smaller predicted time of its slowest rank WITH the group-local all-reduces counted -- for every
+    band a rank shares with others, 20 us + 2 (m - 1) / m * bytes of that band's partial outputs at 50 GB/s (one xGMI link per
+    pair; the link model is unmeasured).  A band is therefore split only when that pays for the extra collective: config 3 on
+    4 ranks is one band per GPU (930 us predicted against 1110 us for the equal-cost chunks, which cut 2A / 2B / 2C
+    across ranks), on 8 ranks two equal parts per band (655 against 721 us: the chunks put most ranks into TWO groups).
+    ``SURFH_PARTITION=balanced``: the compute-only rule of round 2 (whole bands / equal parts when balanced to 5 %, else the
+    chunks).  Returns (assignment, per-rank compute loads, per-rank predicted time)."""
     def timed(asg):
-        members = {}
-        for r, units in enumerate(asg):
-            for k, u in units:
-                members.setdefault(k, set()).add(r)
-        loads, times = [], []
-        for r, units in enumerate(asg):
-            load = sum(costs[k] * unit_share(lins, k, u) for k, u in units)
-            comm = 0.0
-            for k in {k for k, _ in units}:
-                m = len(members[k])
-                if m > 1:
-                    comm += 20.0 + 2.0 * (m - 1) / m * ybytes[k] / 50e3
-            loads.append(load)
-            times.append(load + comm)
-        return loads, times
+        return assignment_times(costs, lins, ybytes, asg)
     cand, bal = partition_lambda(costs, world), partition_balanced(costs, lins, world)
     (lc, tc), (lb, tb) = timed(cand), timed(bal)
-    if os.environ.get("SURFH_PARTITION", "balanced") == "comm":
-        return (cand, lc, tc) if max(tc) <= max(tb) else (bal, lb, tb)
-    return (cand, lc, tc) if max(lc) <= 1.05 * max(lb) else (bal, lb, tb)
+    if os.environ.get("SURFH_PARTITION", "comm") == "balanced":
+        return (cand, lc, tc) if max(lc) <= 1.05 * max(lb) else (bal, lb, tb)
+    return (cand, lc, tc) if max(tc) <= max(tb) else (bal, lb, tb)
 
 
-def plan_assignment(prob: dict, world: int, split: str = "lambda"):
+def plan_assignment(prob: dict, world: int, split: str = "lambda", with_times: bool = False):
     """The unit assignment ``DistributedFusion`` uses for `world` ranks, with the predicted cost of every rank:
-    ``(assignment, loads, imbalance)``, imbalance = max load / mean load - 1 (SURVEY.md 8e gate: <= 15 %).  Host only."""
+    ``(assignment, loads, imbalance)``, imbalance = max load / mean load - 1 of the compute loads (``with_times``: a fourth
+    entry, the predicted per-rank times with the group-local all-reduces -- what the assignment is chosen by).  Host only."""
     from .geometry import ChannelGeometry
     ifus, pts = prob["ifus"], prob["pointings"]
     n_pix = len(prob["alpha_axis"])
@@ -265,11 +272,14 @@ def plan_assignment(prob: dict, world: int, split: str = "lambda"):
     if split == "lambda":
         lins = [g.wslice.stop - g.wslice.start for g in geos]
         ybytes = [4 * int(np.prod(g.oshape)) for g in geos]
-        asg, loads, _ = choose_lambda_assignment(costs, lins, ybytes, world)
+        asg, loads, times = choose_lambda_assignment(costs, lins, ybytes, world)
     else:
         asg = partition_units(costs, [len(p) for p in pts], world)
         loads = [sum(costs[k] * len(sel) / len(pts[k]) for k, sel in r) for r in asg]
+        times = list(loads)
     mean = sum(loads) / len(loads)
+    if with_times:
+        return asg, loads, max(loads) / mean - 1.0, times
     return asg, loads, max(loads) / mean - 1.0
 
 
@@ -287,6 +297,10 @@ class DistributedFusion:
         import torch
         self.torch = torch
         self.rank, self.world, self.device = rank, world, device
+        # SURFH_FORCE_DIST=1: run the collectives even in a world of one rank (the all-reduce of the normal-equation product on
+        # the plan's stream); =2: also treat every band as shared, i.e. the lambda-split branch (forward, group-local all-reduce
+        # of y, adjoint).  For a one-GPU box, where RCCL can only be exercised with one rank (tests/test_gpu_distributed.py).
+        self.force = int(os.environ.get("SURFH_FORCE_DIST", "0")) if torch.distributed.is_available() and torch.distributed.is_initialized() else 0
         ifus, pts = prob["ifus"], prob["pointings"]
         n_pix = len(prob["alpha_axis"])
         # geometry of every band (cheap) -> costs -> unit assignment, identical on every rank
@@ -301,7 +315,7 @@ class DistributedFusion:
             lins = [g.wslice.stop - g.wslice.start for g in geos]
             ybytes = [4 * int(np.prod(g.oshape)) for g in geos]
             # whole bands / equal parts, or equal-cost contiguous chunks: whichever predicts the faster slowest rank, the
-            # group-local all-reduces of shared bands included
+            # group-local all-reduces of shared bands included (choose_lambda_assignment)
             self.assignment, _, self.predicted_us = choose_lambda_assignment(self.costs, lins, ybytes, world)
             self.units = self.assignment[rank]
             my_ifus = [ifus[k] for k, _ in self.units]
@@ -311,7 +325,7 @@ class DistributedFusion:
             groups = {}
             for k in range(len(ifus)):
                 members = [r for r in range(world) if any(kk == k for kk, _ in self.assignment[r])]
-                if len(members) > 1:
+                if len(members) > 1 or (self.force >= 2 and members):
                     grp = torch.distributed.new_group(ranks=members)
                     if rank in members:
                         groups[k] = grp
@@ -346,7 +360,17 @@ class DistributedFusion:
         # recurrences and r.r are those of the maps.  SURFH_SPECTRAL_CG=0: vectors are the maps.
         self.spec = bool(getattr(self.model, "spec_supported", None)) and self.model.spec_supported() and \
             os.environ.get("SURFH_SPECTRAL_CG", "1") != "0"
+        if world > 1 or self.force:
+            # every rank decides from its own plan (transform kernels, pitch limits, prior): the vectors that are all-reduced
+            # must have one basis and one length everywhere, so the ranks agree on the weakest answer
+            flag = torch.tensor([1 if self.spec else 0], dtype=torch.int32, device=self.dev if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+            self.spec = bool(int(flag.item()))
         self.nv = self.model.spec_size if self.spec else self.n      # floats of a solver vector
+        if world > 1 or self.force:
+            nvs = torch.tensor([self.nv, -self.nv], dtype=torch.int64, device=self.dev if torch.distributed.get_backend() == "nccl" else "cpu")
+            torch.distributed.all_reduce(nvs, op=torch.distributed.ReduceOp.MAX)
+            assert int(nvs[0]) == self.nv and int(nvs[1]) == -self.nv, "ranks disagree on the length of the solver's vectors"
         self._ytmp = None
         if split == "lambda" and getattr(self, "_band_groups", None):
             idx = np.cumsum([0] + [int(np.prod(c.oshape)) for c in self.model.channels]) if hasattr(self.model, "channels") \
@@ -356,7 +380,7 @@ class DistributedFusion:
                     self.unit_groups.append((int(idx[u]), int(idx[u + 1]), self._band_groups[k]))
 
     def _allreduce(self, t):
-        if self.world > 1:
+        if self.world > 1 or self.force:
             self.torch.distributed.all_reduce(t)
 
     def _reduce_shared(self, y):
@@ -387,7 +411,7 @@ class DistributedFusion:
         if self.spec:
             m = self.model
             if self.group is None:
-                if self.world == 1:
+                if self.world == 1 and not self.force:
                     m.normal_spec_dev(d, q, mu, mu_reg)            # prior folded into the adjoint's last kernel
                     return
                 m.normal_spec_dev(d, q, mu, 0.0)

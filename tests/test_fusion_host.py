@@ -46,18 +46,27 @@ def test_band_wavelength_tables_are_the_reference_tables():
     assert np.array_equal(np.linspace(lo, hi, int(n))[::500], p3["wavel"])
 
 
-def test_partition_imbalance_gate():
-    """the assignment the multi-GPU driver will use for 2, 4 and 8 ranks on config 3 (4 bands) and for 8 ranks on
-    config 4 (12 bands, npix 501): every cube plane of every band owned exactly once, predicted per-rank cost within 15 %."""
+def test_partition_choice(monkeypatch):
+    """the assignment the multi-GPU driver will use for 2, 4 and 8 ranks on config 3 (4 bands) and on config 4
+    (12 bands, npix 501): every cube plane of every band owned exactly once; config 3 on 4 ranks is one band per GPU (north_star);
+    a band is split only where the predicted time of the slowest rank, the group-local all-reduce of the split band's partial
+    outputs included, is lower than without the split; the compute-only rule (SURFH_PARTITION=balanced) stays within 15 %."""
     from surfh_amd.fusion import plan_assignment
     p3 = synth.config3(geometry_only=True)
     p4 = synth.config4(n_pix=501, geometry_only=True)
     for prob, worlds in ((p3, (2, 4, 8)), (p4, (2, 4, 8))):
         for world in worlds:
-            asg, loads, imb = plan_assignment(prob, world)
-            print(len(prob["ifus"]), "bands on", world, "ranks: loads", [round(v) for v in loads], f"imbalance {imb:.3f}")
+            monkeypatch.setenv("SURFH_PARTITION", "balanced")
+            asg_b, loads_b, imb_b, times_b = plan_assignment(prob, world, with_times=True)
+            monkeypatch.delenv("SURFH_PARTITION")
+            asg, loads, imb, times = plan_assignment(prob, world, with_times=True)
+            print(len(prob["ifus"]), "bands on", world, "ranks: loads", [round(v) for v in loads], f"compute imbalance {imb:.3f}, slowest rank "
+                  f"{max(times):.0f} us (compute-balanced chunks: {max(times_b):.0f} us, imbalance {imb_b:.3f})")
             assert len(asg) == world and all(len(r) > 0 for r in asg)
-            assert imb <= 0.15, (world, loads)
+            assert imb_b <= 0.15, (world, loads_b)
+            assert max(times) <= max(times_b) + 1e-9
+            if prob is p3 and world == 4:
+                assert sorted(r[0] for r in asg) == [(0, (0, 1)), (1, (0, 1)), (2, (0, 1)), (3, (0, 1))]
             # coverage: the lambda parts of every band tile its window exactly
             from surfh_amd.geometry import ChannelGeometry
             from surfh_amd import instru
