@@ -92,12 +92,150 @@ def cpu_baseline(cfg_name: str, budget_s: float):
             "seconds_per_sample_iteration": t_it}
 
 
+def main_config5(args):
+    """BASELINE.json configs[4]: the 2-D deconvolution path (scripts/deconvolution_mrs_noRotation.py:100-212 -> criterion_2D.py ->
+    qmm.lcg) on 512 x 512 x 2048: band 1C geometry without rotation, four pointings, one independent regularised 2-D problem per
+    wavelength plane, all planes batched in one plan.  A step = one CG iteration of every plane (forward + adjoint of MRSBlurred,
+    first-difference priors, per-plane step lengths).  The planes do not couple: N ranks take 2048 / N planes each and nothing is
+    exchanged (replicas on disjoint plane ranges)."""
+    import torch
+    import torch.distributed as dist
+    from oracle import surfh_oracle as orc            # problem constants only (axes, PSF formula); nothing of it is timed
+    from surfh_amd import instru, synth
+    from surfh_amd.spectro_blind_rectangle import MRSBlurred
+    rank, world, local = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    N, Lc = 512, 2048
+    lo, hi = Lc * rank // world, Lc * (rank + 1) // world            # this rank's planes
+    t0 = time.time()
+    ax = synth.axes(N)
+    wav = np.linspace(6.53, 7.65, Lc)[lo:hi]
+    sotf = synth.ir2fr(synth.gaussian_psf(wav, synth.STEP), (N, N))
+    ifu = instru.IFU(fov=instru.FOV(3.2 / 3600, 3.7 / 3600, origin=instru.Coord(0, 0), angle=0.0), det_pix_size=0.196, n_slit=21,
+                     w_blur=instru.SpectralBlur(3355.0), pce=None, wavel_axis=np.linspace(6.6, 7.6, 10), name="1C")
+    sd = synth.STEP_DEG
+    pts = instru.CoordList([instru.Coord(a, b) for a, b in [(0.0, 0.0), (2 * sd, -3 * sd), (-4 * sd, 1 * sd), (3 * sd, 5 * sd)]])
+    ts = torch.cuda.Stream(device=local)
+    mb = MRSBlurred(sotf, ax, ax, ifu, sd, pts, device=local, stream=ts.cuda_stream)
+    log(f"[rank {rank}] planes [{lo}, {hi}); problem + plan in {time.time() - t0:.1f}s; oshape {mb.oshape}")
+    dev = torch.device(f"cuda:{local}")
+    with torch.cuda.stream(ts):
+        g = torch.Generator(device=dev).manual_seed(19940407 + rank)
+        truth = torch.rand((hi - lo, N, N), generator=g, device=dev, dtype=torch.float32)
+        y = torch.empty(int(np.prod(mb.oshape)), dtype=torch.float32, device=dev)
+        mb.forward_dev(truth, y)
+        y += torch.randn(y.shape, generator=g, device=dev, dtype=torch.float32) * (1e-2 * y.square().mean().sqrt())
+        x = torch.zeros_like(truth)
+        mu, mu_reg = 1.0, 0.05
+        mb.cg_begin_dev(y, x, mu, mu_reg)
+    ts.synchronize()
+    rr0 = mb.cg_rr()
+    prof_all, n_all = {}, 0
+    with torch.cuda.stream(ts):
+        for i in range(args.warmup):
+            if not args.no_profile and i == min(1, args.warmup - 1):
+                ts.synchronize()
+                mb.profile_reset(); mb.profile_enable(True)
+                n_all = args.warmup - i
+            mb.cg_step_dev(1)
+    if n_all:
+        prof_all = mb.profile()
+        mb.profile_enable(False)
+
+    def fence():
+        ts.synchronize()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    with torch.cuda.stream(ts):
+        mb.cg_step_dev(args.steps)
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([el], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    rr1 = mb.cg_rr()
+    if rank == 0:
+        for name, (cnt, ms) in sorted(prof_all.items(), key=lambda kv: -kv[1][1]):
+            log(f"[prof warm-up] {name:28s} launches {cnt:5d}  avg {ms / max(cnt, 1):8.4f} ms  per-step {ms / n_all:8.4f} ms")
+        Nf = N * (N // 2 + 1)
+        Lr = hi - lo
+        stage = {k: v for k, v in prof_all.items() if k.startswith(("dft_", "specmix_"))}
+        t_stage = sum(v[1] for v in stage.values()) * 1e-3 / max(n_all, 1)
+        # per plane and direction the chain reads the image, reads the OTF and writes the blurred image: 2 N^2 4 + Nf 8 bytes
+        b_stage = 2.0 * Lr * (2 * N * N * 4 + Nf * 8)
+        dft = {k: v for k, v in prof_all.items() if k.startswith("dft_")}
+        dom_cnt = sum(v[0] for v in dft.values())
+        dom_ms = sum(v[1] for v in dft.values())
+        roof = None
+        if dom_cnt:
+            # a step holds four 2-D transforms (x -> spectrum and product -> image, in each direction) = eight pass launches
+            bytes_launch = 0.5 * Lr * (Nf * 8 + N * N * 4)
+            ach = bytes_launch / (dom_ms / dom_cnt * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                    "traffic_source": None, "kernel": "dft_ct_kernel" if any(k.startswith("dft_ct_") for k in dft) else "dft_rx3_kernel",
+                    "launches": dom_cnt, "avg_ms": dom_ms / dom_cnt,
+                    "note": "per launch: half of a 2-D transform's algorithmic bytes, planes x (N (N/2+1) 8 + N^2 4) / 2; HIP-event times of the "
+                            f"{n_all} warm-up step(s)"}
+        out = {"metric": "CG-iterations/sec (forward+adjoint) on 512x512x2048 cube, 2-D deconvolution path", "value": args.steps / el, "unit": "it/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None,
+               "dtype": "f32 (storage and accumulation; the DFT passes as 2-piece fp16 splits, 3 products per fp32 product, on the 16-bit matrix cores)",
+               "data": "synthetic",
+               "config": {"workload": "config5: 2-D deconvolution (MRSBlurred, band 1C geometry, no rotation, 4 pointings) of 2048 independent "
+                                      "512x512 planes, mu_reg=0.05, x0=0", "parallelism": f"{world} rank(s), {Lr} planes each, no exchange",
+                          "rr_median_first_last": [float(np.median(rr0)), float(np.median(rr1))]},
+               "roofline": roof,
+               "roofline_fft_conv_stage": {"bound": "hbm", "achieved": b_stage / t_stage / 1e9 if t_stage else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": b_stage / t_stage / 1e9 / HBM_PEAK_GBS if t_stage else None, "ms_per_step": t_stage * 1e3,
+                                           "kernel": "+".join(sorted(stage)),
+                                           "note": "whole stage (transform passes + OTF products) against 2 x planes x (2 N^2 4 + Nf 8) bytes per step: "
+                                                   "per direction the image read, the OTF read, the blurred image written"},
+               "stage_ms_per_step": {k: round(v[1] / max(n_all, 1), 4) for k, v in sorted(prof_all.items(), key=lambda kv: -kv[1][1])},
+               "cpu_baseline": None}
+        if world == 1 and args.cpu_seconds > 0:
+            try:      # the oracle's 2-D operator (float64 port) on a few planes, all host cores through scipy.fft / BLAS
+                sel = list(range(0, Lr, max(1, Lr // 8)))[:8]
+                spec = orc.ChannelSpec(3.2 / 3600, 3.7 / 3600, (0.0, 0.0), 0.0, 0.196, 21, 3355.0, np.linspace(6.6, 7.6, 10), "1C")
+                bo = orc.BlurredOracle(sotf[sel], ax, ax, spec, sd, [(0.0, 0.0), (2 * sd, -3 * sd), (-4 * sd, 1 * sd), (3 * sd, 5 * sd)])
+                d = np.random.default_rng(0).standard_normal((len(sel), N, N))
+                bo.adjoint(bo.forward(d))
+                tt = []
+                while len(tt) < 3 and (not tt or sum(tt) + tt[-1] < args.cpu_seconds):
+                    t1 = time.time()
+                    q = bo.adjoint(bo.forward(d))
+                    q = q + 0.05 * (orc.diff_r_t(orc.diff_r(d)) + orc.diff_c_t(orc.diff_c(d)))
+                    tt.append(time.time() - t1)
+                t_it = float(np.median(tt))
+                out["cpu_baseline"] = {"value": len(sel) / Lr / t_it, "unit": "it/s", "cores": os.cpu_count(), "kind": "port",
+                                       "sample": f"oracle normal operator + priors on {len(sel)} of {Lr} planes (independent problems: full-size rate = "
+                                                 f"sample rate x {len(sel)}/{Lr}); {len(tt)} reps, median {t_it:.2f}s",
+                                       "seconds_per_sample_iteration": t_it}
+            except Exception as e:
+                out["cpu_baseline"] = {"value": None, "error": repr(e)}
+        print(json.dumps(out), flush=True)
+    mb.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400, help="timed CG iterations (400 x 3 ms: the timed region is >= 1 s and holds the residual refreshes of qmm.lcg, one every 50 iterations)")
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--config", default="3", choices=["2", "3", "4"])
+    ap.add_argument("--config", default="3", choices=["2", "3", "4", "5"])
     ap.add_argument("--cpu-seconds", type=float, default=25.0, help="budget of the CPU baseline leg (0 = skip)")
     ap.add_argument("--no-profile", action="store_true", help="do not record per-kernel HIP events in the timed region")
     ap.add_argument("--no-verify", action="store_true", help="skip the randn dot test on the float64-accumulating verification plan")
@@ -116,6 +254,8 @@ def main():
                                   "(SURFH_PARTITION=balanced: compute-only rule, imbalance gate 15 %); link model unmeasured"}))
         return
 
+    if args.config == "5":
+        return main_config5(args)
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))

@@ -184,6 +184,15 @@ int surfh_cg_planes(surfh_plan *plan, const float *y, double mu, double mu_reg, 
 int surfh_mmmg_planes(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,
                       double tol, int32_t refresh, float *x, double *grad_norm, int32_t *nit);
 
+/* The plane-wise CG with the data and the iterate resident on the device and no host synchronisation inside the loop (drivers
+ * that keep their cubes in HBM; bench.py --config 5).  begin: b = mu A^T y, r = b - Q x, d = r, with x_dev [Lc][Na][Nb] the start
+ * and from then on the current iterate (the caller's buffer, updated in place by step);  step: `iters` more iterations of the loop
+ * of surfh_cg_planes (residual recomputed every `refresh` iterations, counted from begin);  rr: r_l.r_l of the current iterate,
+ * [Lc] doubles on the host (synchronises the plan's stream).  All pointers except rr_host are device pointers. */
+int surfh_cg_planes_begin_dev(surfh_plan *plan, const float *y_dev, double mu, double mu_reg, float *x_dev);
+int surfh_cg_planes_step_dev(surfh_plan *plan, int32_t iters, int32_t refresh);
+int surfh_cg_planes_rr(surfh_plan *plan, double *rr_host);
+
 /* the two plane-wise solvers with qmm's per-iteration callback (criterion_2D.py:163-225): grad_norm is the trace so far,
  * [it + 1][Lc] values, x the current iterate [Lc][Na][Nb] on the host; a non-zero return stops the loop */
 int surfh_cg_planes_cb(surfh_plan *plan, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter,

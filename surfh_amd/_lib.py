@@ -48,7 +48,7 @@ EXPORTS = [
     "surfh_stream", "surfh_forward", "surfh_adjoint", "surfh_adjoint_ref", "surfh_fwadj", "surfh_forward_dev",
     "surfh_adjoint_dev", "surfh_adjoint_ref_dev", "surfh_fwadj_dev", "surfh_wct_forward", "surfh_wct_adjoint",
     "surfh_wct_fwadj", "surfh_wct_expsol", "surfh_tst_create", "surfh_tst_destroy", "surfh_tst_forward",
-    "surfh_tst_adjoint", "surfh_tst_fwadj", "surfh_tst_last_error", "surfh_cg", "surfh_cg_cb", "surfh_mmmg", "surfh_cg_planes", "surfh_mmmg_planes", "surfh_cg_planes_cb", "surfh_mmmg_planes_cb", "surfh_maps_to_cube", "surfh_cube_to_maps", "surfh_normal_dev",
+    "surfh_tst_adjoint", "surfh_tst_fwadj", "surfh_tst_last_error", "surfh_cg", "surfh_cg_cb", "surfh_mmmg", "surfh_cg_planes", "surfh_mmmg_planes", "surfh_cg_planes_cb", "surfh_mmmg_planes_cb", "surfh_cg_planes_begin_dev", "surfh_cg_planes_step_dev", "surfh_cg_planes_rr", "surfh_maps_to_cube", "surfh_cube_to_maps", "surfh_normal_dev",
     "surfh_prior_add_dev", "surfh_spec_supported", "surfh_spec_size", "surfh_to_spec_dev", "surfh_from_spec_dev", "surfh_forward_spec_dev",
     "surfh_adjoint_spec_dev", "surfh_normal_spec_dev", "surfh_prior_spec_add_dev", "surfh_set_prior", "surfh_dot_dev", "surfh_cg_step_dev", "surfh_cg_dir_dev", "surfh_cg_iter_dev", "surfh_residual_dev",
     "surfh_cg_begin_dev", "surfh_cg_iter_nosync_dev", "surfh_cg_xupdate_nosync_dev", "surfh_cg_refresh_nosync_dev", "surfh_cg_trace",
@@ -95,6 +95,9 @@ def load():
                               c_float_p, c_double_p, c_int32_p, CG_CALLBACK, vp]
     L.surfh_mmmg.argtypes = L.surfh_cg_cb.argtypes
     L.surfh_mmmg_planes.argtypes = L.surfh_cg_planes.argtypes
+    L.surfh_cg_planes_begin_dev.argtypes = [vp, vp, C.c_double, C.c_double, vp]
+    L.surfh_cg_planes_step_dev.argtypes = [vp, C.c_int32, C.c_int32]
+    L.surfh_cg_planes_rr.argtypes = [vp, c_double_p]
     L.surfh_cg_planes_cb.argtypes = L.surfh_cg_cb.argtypes
     L.surfh_mmmg_planes_cb.argtypes = L.surfh_cg_cb.argtypes
     L.surfh_maps_to_cube.argtypes = [vp, c_double_p, C.c_int32, C.c_int32, c_float_p, c_float_p]

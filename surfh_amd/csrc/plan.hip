@@ -206,6 +206,11 @@ struct surfh_plan {
     double *dscal = nullptr, *dscratch = nullptr;   // [8] device scalars, [1024] partial sums
     double *cg_hist = nullptr;                     // device-resident r.r trace of the no-host-sync CG blocks (CG_HIST_CAP entries)
     int cg_hist_n = 0;
+    // plane-wise CG with device-resident data (surfh_cg_planes_begin_dev / _step_dev): per-plane scalars [3][Lc], the caller's iterate
+    double *pl_sc = nullptr;
+    float *pl_x = nullptr;
+    double pl_mu = 1.0, pl_mu_reg = 0.0;
+    int pl_it = 0;
     // profiling
     bool prof = false;
     std::string prof_filter;                     // non-empty: only stages whose name starts with it are bracketed by events
@@ -1536,6 +1541,7 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipFree(p->dscal);
     hipFree(p->dscratch);
     hipFree(p->cg_hist);
+    hipFree(p->pl_sc);
     for (auto &c : p->ch) {
         for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
         hipFree(c.W16);
@@ -2616,6 +2622,64 @@ int surfh_cg_planes_cb(surfh_plan *p, const float *y, double mu, double mu_reg, 
 int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, const float *x0, int32_t max_iter, double tol,
                     int32_t refresh, float *x, double *grad_norm, int32_t *nit) {
     return surfh_cg_planes_cb(p, y, mu, mu_reg, x0, max_iter, tol, refresh, x, grad_norm, nit, nullptr, nullptr);
+}
+
+// ---- the same loop with the data and the iterate resident on the device and no host synchronisation inside: begin (b = mu A^T y,
+// r = b - Q x, d = r), any number of step calls, r.r per plane on request.  x_dev stays the caller's buffer and holds the iterate.
+int surfh_cg_planes_begin_dev(surfh_plan *p, const float *y_dev, double mu, double mu_reg, float *x_dev) {
+    if (!p || !y_dev || !x_dev) return fail("null argument");
+    if (p->T != 0) return fail("surfh_cg_planes is the solver of the plane-wise (no template) model; use surfh_cg with templates");
+    if (p->ch.empty()) return fail("plan has no channel");
+    HIP_OK(hipSetDevice(p->dev));
+    if (ensure_cg(p)) return 1;
+    hipStream_t s = p->stream;
+    const int L = p->Lc;
+    const long npix = (long)p->Na * p->Nb, n = p->isize;
+    if (!p->pl_sc) HIP_OK(hipMalloc((void **)&p->pl_sc, (size_t)3 * L * sizeof(double)));
+    p->pl_x = x_dev; p->pl_mu = mu; p->pl_mu_reg = mu_reg; p->pl_it = 0;
+    if (adjoint_dev(p, y_dev, p->cg_b, false)) return 1;
+    if (mu != 1.0) LAUNCH_OK(launch_scale(s, p->cg_b, n, (float)mu));
+    if (normal_dev(p, x_dev, p->cg_q, mu)) return 1;
+    if (mu_reg != 0.0) LAUNCH_OK(prior_add(p, s, x_dev, p->cg_q, L, (float)mu_reg));
+    LAUNCH_OK(launch_residual(s, p->cg_r, p->cg_b, p->cg_q, n));
+    HIP_OK(hipMemcpyAsync(p->cg_d, p->cg_r, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    LAUNCH_OK(launch_dot_planes(s, p->cg_r, p->cg_r, L, npix, p->pl_sc));
+    return 0;
+}
+int surfh_cg_planes_step_dev(surfh_plan *p, int32_t iters, int32_t refresh) {
+    if (!p || !p->pl_sc || !p->pl_x) return fail("surfh_cg_planes_begin_dev has not been called");
+    HIP_OK(hipSetDevice(p->dev));
+    hipStream_t s = p->stream;
+    const int L = p->Lc;
+    const long npix = (long)p->Na * p->Nb, n = p->isize;
+    double *rr = p->pl_sc, *dq = p->pl_sc + L, *rrn = p->pl_sc + 2 * L;
+    float *x = p->pl_x;
+    auto Q = [&](const float *v, float *out) -> int {
+        if (normal_dev(p, v, out, p->pl_mu)) return 1;
+        if (p->pl_mu_reg != 0.0) LAUNCH_OK(prior_add(p, s, v, out, L, (float)p->pl_mu_reg));
+        return 0;
+    };
+    for (int i = 0; i < iters; ++i, ++p->pl_it) {
+        if (Q(p->cg_d, p->cg_q)) return 1;
+        LAUNCH_OK(launch_dot_planes(s, p->cg_d, p->cg_q, L, npix, dq));
+        if (refresh > 0 && p->pl_it % refresh == 0) {
+            LAUNCH_OK(launch_cg_step_planes(s, x, p->cg_r, p->cg_d, p->cg_q, L, npix, rr, dq, rrn, 0));
+            if (Q(x, p->cg_q)) return 1;
+            LAUNCH_OK(launch_residual(s, p->cg_r, p->cg_b, p->cg_q, n));
+            LAUNCH_OK(launch_dot_planes(s, p->cg_r, p->cg_r, L, npix, rrn));
+        } else {
+            LAUNCH_OK(launch_cg_step_planes(s, x, p->cg_r, p->cg_d, p->cg_q, L, npix, rr, dq, rrn, 1));
+        }
+        LAUNCH_OK(launch_cg_dir_planes(s, p->cg_d, p->cg_r, L, npix, rrn, rr));      // also rr = rr'
+    }
+    return 0;
+}
+int surfh_cg_planes_rr(surfh_plan *p, double *rr_host) {
+    if (!p || !p->pl_sc || !rr_host) return fail("surfh_cg_planes_begin_dev has not been called");
+    HIP_OK(hipSetDevice(p->dev));
+    HIP_OK(hipMemcpyAsync(rr_host, p->pl_sc, (size_t)p->Lc * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipStreamSynchronize(p->stream));
+    return 0;
 }
 
 // ---- 3MG on independent planes: what `method = "qmm"` of the 2-D deconvolution driver runs

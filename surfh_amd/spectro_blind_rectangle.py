@@ -179,6 +179,37 @@ class MRSBlurred(LinOp):
         ``callback(it, grad_norm, x)`` as for ``spectroSigRLSCT.cg``."""
         return self._solve(self._L.surfh_cg_planes_cb, data, mu, mu_reg, x0, max_iter, tol, refresh, callback)
 
+    # ---- instrumentation (HIP events on the plan's stream, as spectroSigRLSCT) -----------------------------
+    def profile_enable(self, on=True):
+        _lib.check(self._L.surfh_profile_enable(self._plan, 1 if on else 0))
+
+    def profile_reset(self):
+        _lib.check(self._L.surfh_profile_reset(self._plan))
+
+    def profile(self) -> dict:
+        out = {}
+        for i in range(self._L.surfh_profile_count(self._plan)):
+            name, cnt, ms = C.c_char_p(), C.c_int64(), C.c_double()
+            _lib.check(self._L.surfh_profile_get(self._plan, i, C.byref(name), C.byref(cnt), C.byref(ms)))
+            out[name.value.decode()] = (cnt.value, ms.value)
+        return out
+
+    # the same loop on device tensors (torch), no host synchronisation inside: see include/surfh_amd.h
+    def forward_dev(self, x_t, y_t):
+        _lib.check(self._L.surfh_forward_dev(self._plan, C.c_void_p(x_t.data_ptr()), C.c_void_p(y_t.data_ptr())))
+
+    def cg_begin_dev(self, y_t, x_t, mu=1.0, mu_reg=0.0):
+        """``x_t`` [n_planes, Na, Nb] float32 on the plan's device: the start, then the current iterate (updated in place)."""
+        _lib.check(self._L.surfh_cg_planes_begin_dev(self._plan, C.c_void_p(y_t.data_ptr()), float(mu), float(mu_reg), C.c_void_p(x_t.data_ptr())))
+
+    def cg_step_dev(self, iters=1, refresh=50):
+        _lib.check(self._L.surfh_cg_planes_step_dev(self._plan, int(iters), int(refresh)))
+
+    def cg_rr(self):
+        out = np.zeros(self.n_planes, dtype=np.float64)
+        _lib.check(self._L.surfh_cg_planes_rr(self._plan, _lib.dptr(out)))
+        return out
+
     def mmmg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):
         """Device-resident 3MG on the same criterion (`qmm.mmmg` restated for quadratic objectives) -- what the 2-D
         deconvolution driver's ``method = "qmm"`` runs (scripts/deconvolution_mrs_noRotation.py:199-212).  Same returns as
