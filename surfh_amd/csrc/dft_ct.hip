@@ -381,6 +381,11 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
             const int he = hv;
             const unsigned ldc4 = (unsigned)ldc_o * 4u;
             const unsigned vlo = (unsigned)he * ldc4 + (unsigned)l31 * 4u, vmi = (unsigned)(1 - he) * ldc4 + (unsigned)l31 * 4u;
+            // store descriptors span the two rows of a row pair; a masked lane (voffset) or a row pair beyond the row limit
+            // (soffset) lands outside and is dropped by the range check: no exec-mask juggling around the stores
+            const int wrange = (int)(ldc4 + 256u);
+            constexpr unsigned VOOB = 0x7FFFFF00u;
+            const long kstride = (long)M * ldc_o;
 #pragma unroll
             for (int ph = 0; ph < 2 * MAXMT; ++ph) {
                 if (ph < nph) {                                    // wave- and workgroup-uniform
@@ -442,16 +447,21 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
                             }
                             if (EP == DFT_CT_STORE) {
                                 // rows (r0 + h) + M k1 and (M - r0 - 1 + (1 - h)) + M k1: scalar row base per store, the half in the lane offset
+                                const unsigned vp_ = okr ? vlo : VOOB, vm_ = okm ? vmi : VOOB;
+                                const float *pp_ = dtile + (long)r0 * ldc_o, *pm_ = dtile + (long)(M - r0 - 1) * ldc_o;
 #pragma unroll
                                 for (int k1 = 0; k1 < R; ++k1) {
                                     if (!(CT_EXP & 2)) {
-                                        const __amdgpu_buffer_rsrc_t wp_ = CT_RSRC(dtile + (long)(r0 + M * k1) * ldc_o);
-                                        const __amdgpu_buffer_rsrc_t wm_ = CT_RSRC(dtile + (long)(M - r0 - 1 + M * k1) * ldc_o);
-                                        const int kp_ = r + M * k1, km_ = rm + M * k1;
-                                        const int fp_ = kp_ < N - kp_ ? kp_ : N - kp_, fm_ = km_ < N - km_ ? km_ : N - km_;
-                                        if (okr && fp_ <= rlim) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xp[k1]), wp_, (int)vlo, 0, 0);
-                                        if (okm && fm_ <= rlim) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xm[k1]), wm_, (int)vmi, 0, 0);
+                                        // a row pair is stored if either of its rows is inside the limit (a superset of what is read)
+                                        const int kp0 = r0 + M * k1, km0 = M - r0 - 1 + M * k1;        // first rows of the two pairs
+                                        const int fp_ = kp0 < N - kp0 - 1 ? kp0 : N - kp0 - 1, fm_ = km0 < N - km0 - 1 ? km0 : N - km0 - 1;
+                                        const __amdgpu_buffer_rsrc_t wp_ = __builtin_amdgcn_make_buffer_rsrc((void *)pp_, 0, wrange, 0x00020000);
+                                        const __amdgpu_buffer_rsrc_t wm_ = __builtin_amdgcn_make_buffer_rsrc((void *)pm_, 0, wrange, 0x00020000);
+                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xp[k1]), wp_, (int)vp_, fp_ <= rlim ? 0 : 0x40000000, 0);
+                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xm[k1]), wm_, (int)vm_, fm_ <= rlim ? 0 : 0x40000000, 0);
                                     }
+                                    pp_ += kstride;
+                                    pm_ += kstride;
                                 }
                             } else {
                                 // the two Hermitian spectra of the packed pair: partner of k = r + M k1 is N - k = (M - r) + M (R - 1 - k1)
