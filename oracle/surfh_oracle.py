@@ -899,6 +899,34 @@ class BlurredOracle:
         return out if self.batched else out[0]
 
 
+    def data_to_img(self, data):
+        """``MRSBlurred.data_to_img`` (surfh/Models/spectro_blind_rectangle.py:240-283): the slit data spread evenly over the
+        slit's beta columns, put back on the local grid, box-summed, thresholded (< 1 -> 0) with the reference's two column
+        patches (local columns 5 <- 6 and 153 <- 152: the local grid must have at least 154 columns), placed in the image
+        at every pointing.  Returns (mean over the pointings that cover a pixel, sum over pointings).  The reference leaves the
+        mean of uncovered pixels uninitialised (``np.divide(..., where=...)`` without ``out``); 0 here."""
+        if self.batched:
+            raise ValueError("data_to_img is defined for a single image")
+        d = np.asarray(data, dtype=np.float64).reshape(self.slices_shape)
+        na, nb = len(self.la), len(self.lb)
+        cum = np.zeros((len(self.crops),) + self.ishape)
+        for p, (a0, a1, b0, b1) in enumerate(self.crops):
+            local = np.zeros((na, nb))
+            for s, (sa0, sa1, sb0, sb1) in enumerate(self.slit_slices):
+                over = np.repeat(d[p, s][:, None], self.npix_b, axis=1) / self.npix_b
+                bts = np.zeros((sa1 - sa0, sb1 - sb0))
+                bts[: self.n_out * self.srf: self.srf, :] = over
+                local[sa0:sa1, sb0:sb1] += bts * self.slit_weights[s]
+            st = self._box(local, t=True)
+            st[st < 1] = 0
+            st[:, 5] = st[:, 6]
+            st[:, 153] = st[:, 152]
+            cum[p, a0:a1, b0:b1] = st
+        valid = np.sum(cum != 0, axis=0)
+        total = np.sum(cum, axis=0)
+        return np.divide(total, valid, out=np.zeros(self.ishape), where=valid != 0), total
+
+
 # ----------------------------------------------------------------------------
 # Fourier-domain fused W.C.T operator: Model_WCT (surfh/Models/mixing.py:131-272, di = dj = 1)
 # ----------------------------------------------------------------------------

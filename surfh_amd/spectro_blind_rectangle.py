@@ -171,6 +171,40 @@ class MRSBlurred(LinOp):
     def adjoint(self, data):
         return self._call(self._L.surfh_adjoint, data, self.osize, self.ishape)
 
+    def data_to_img(self, data):
+        """The reference's quick-look back-projection of slit data (spectro_blind_rectangle.py:240-283; called by
+        scripts/simulate_deconvolution_mrs_rectangle.py:193 and scripts/deconvolution_mrs_single_wavelength.py:159,194): every
+        sample spread evenly over its slit's beta columns, put back on the local grid (slit windows with their beta-edge
+        weights), summed over the srf-row window (the transposed box), values below 1 zeroed and local columns 5 / 153
+        overwritten by their neighbours 6 / 152 as the reference does (so the local grid needs >= 154 columns, as there),
+        placed in the image at each pointing.  Returns ``(weighted_mean, global_img)``: the mean over the pointings that
+        cover a pixel (0 where none does; the reference leaves those entries uninitialised) and the plain sum.
+        Host NumPy: a plotting aid on one image, not part of the operator."""
+        if self.batched:
+            raise ValueError("data_to_img is defined for a single image")
+        if self.local_im_shape[1] < 154:
+            raise IndexError(f"data_to_img patches local columns 5 and 153: the local grid has {self.local_im_shape[1]} columns")
+        d = np.asarray(data, dtype=np.float64).reshape(self.slices_shape)
+        na, nb = self.local_im_shape
+        nbs, n_out = self.npix_slit_beta_width, self.slices_shape[2]
+        cum = np.zeros((len(self.crops),) + self.imshape)
+        for p, (a0, a1, b0, b1) in enumerate(self.crops):
+            local = np.zeros((na, nb))
+            for s in range(self.instr.n_slit):
+                sl = self.get_slit_slices(s)
+                w = self.get_slit_weights(s, sl)[0]
+                bts = np.zeros((sl[0].stop - sl[0].start, sl[1].stop - sl[1].start))
+                bts[: n_out * self.srf: self.srf, :] = np.repeat(d[p, s][:, None], nbs, axis=1) / nbs
+                local[sl[0], sl[1]] += bts * w
+            st = sum(np.roll(local, j, axis=0) for j in range(self.srf))      # transpose of the circular srf-row window sum
+            st[st < 1] = 0
+            st[:, 5] = st[:, 6]
+            st[:, 153] = st[:, 152]
+            cum[p, a0:a1, b0:b1] = st
+        valid = np.sum(cum != 0, axis=0)
+        total = np.sum(cum, axis=0)
+        return np.divide(total, valid, out=np.zeros(self.imshape), where=valid != 0), total
+
     # ---- solver: regularised least squares by CG, one independent 2-D problem per plane -------------------
     def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):
         """Device-resident linear CG on  mu |y - A x|^2 + mu_reg (|Dr x|^2 + |Dc x|^2)  (criterion_2D.py:60-250 with

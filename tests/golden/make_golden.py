@@ -213,6 +213,35 @@ def blurred():
                         slit_w=np.array([rm.get_slit_weights(k, sl[k])[0][0] for k in range(12)]))
 
 
+def blurred_d2i():
+    """MRSBlurred.data_to_img (spectro_blind_rectangle.py:240-283) on the band-1C geometry without rotation (local grid
+    139 x 159: the function patches local columns 5 and 153), 200 x 200 image, three integer-shift pointings; data = the
+    reference's own forward of a random image scaled so that part of the back-projection falls under its threshold of 1."""
+    import importlib
+    import contextlib
+    import io
+    ns = rh.load()
+    mod = importlib.import_module("surfh.Models.spectro_blind_rectangle")
+    orc = problems.orc
+    N = 200
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    spec = orc.ChannelSpec(3.2 / 3600, 3.7 / 3600, (0.0, 0.0), 0.0, 0.196, 21, 3355.0, np.linspace(6.6, 7.6, 10), "1C")
+    sotf = orc.ir2fr(orc.gaussian_psf(np.array([7.0]), problems.STEP), (N, N))[0]
+    s = problems.STEP_DEG
+    pts = [(0.0, 0.0), (5 * s, -7 * s), (-9 * s, 4 * s)]
+    I = ns.instru
+    rm = mod.MRSBlurred(sotf, ax, ax, rh.make_ifu(ns, spec), s, I.CoordList([I.Coord(a, b) for a, b in pts]))
+    x = np.random.default_rng(13).random((N, N)) * np.linspace(0.0, 3.0, N)[None, :]
+    y = np.asarray(rm.forward(x))
+    with contextlib.redirect_stdout(io.StringIO()):          # the function prints a debug line
+        wm, gl = rm.data_to_img(y)
+    cum_valid = np.asarray(gl) != 0
+    np.savez_compressed(os.path.join(HERE, "mrs_blurred_d2i.npz"), y=y, global_img=np.asarray(gl),
+                        weighted_mean=np.where(cum_valid, np.asarray(wm), 0.0), covered=cum_valid, x_seed=np.int64(13),
+                        meta=json.dumps(dict(META, note="weighted_mean is kept only where some pointing contributes (global_img != 0): "
+                                                         "elsewhere the reference returns uninitialised memory")))
+
+
 def wct_inputs():
     orc = problems.orc
     rng = np.random.default_rng(11)
@@ -282,8 +311,7 @@ def projections():
 
 
 if __name__ == "__main__":
-    main()
-    projections()
-    blurred()
-    wct()
-    mixing_st()
+    only = sys.argv[1:]                 # e.g. `make_golden.py blurred_d2i`: regenerate one fixture
+    for fn in (main, projections, blurred, blurred_d2i, wct, mixing_st):
+        if not only or fn.__name__ in only:
+            fn()

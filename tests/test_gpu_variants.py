@@ -69,6 +69,28 @@ def test_mrs_blurred_single_image_vs_reference():
     m.close()
 
 
+def test_mrs_blurred_data_to_img_vs_reference():
+    """The quick-look back-projection ``MRSBlurred.data_to_img`` (spectro_blind_rectangle.py:240-283) of the product class against
+    the reference's own output (tests/golden/mrs_blurred_d2i.npz), on data the HIP forward produced from the same image."""
+    from surfh_amd import instru
+    from surfh_amd.spectro_blind_rectangle import MRSBlurred
+    from test_oracle_golden import d2i_case
+    g = np.load(os.path.join(G, "mrs_blurred_d2i.npz"))
+    N, ax, spec, sotf, s, pts = d2i_case()
+    m = MRSBlurred(sotf, ax, ax, make_ifu(spec), s, instru.CoordList([instru.Coord(a, b) for a, b in pts]))
+    try:
+        wm, gl = m.data_to_img(g["y"])
+        assert np.array_equal(gl != 0, g["covered"])
+        assert rel(gl, g["global_img"]) < 1e-13 and rel(wm, g["weighted_mean"]) < 1e-13
+        x = np.random.default_rng(int(g["x_seed"])).random((N, N)) * np.linspace(0.0, 3.0, N)[None, :]
+        y = m.forward(x)
+        assert rel(y, g["y"]) < TOL
+        wm2, gl2 = m.data_to_img(y)                                   # fp32 data: the threshold may flip a pixel at its edge
+        assert np.mean((gl2 != 0) != g["covered"]) < 1e-3 and rel(gl2, g["global_img"]) < 1e-3
+    finally:
+        m.close()
+
+
 def test_mrs_blurred_batched_over_wavelength():
     N, bo, m = blurred_case(L=40)
     x = np.random.default_rng(1).random((40, N, N))

@@ -247,6 +247,31 @@ def test_mrs_blurred_oracle_vs_reference():
     assert abs(np.vdot(bo.adjoint(u), v) - np.vdot(u, bo.forward(v))) / abs(np.vdot(u, bo.forward(v))) < 1e-12
 
 
+def d2i_case():
+    """The problem of tests/golden/make_golden.py:blurred_d2i (band-1C geometry without rotation, 200 x 200 image)."""
+    N = 200
+    ax = orc.synthetic_axes(N, problems.STEP_DEG)
+    spec = orc.ChannelSpec(3.2 / 3600, 3.7 / 3600, (0.0, 0.0), 0.0, 0.196, 21, 3355.0, np.linspace(6.6, 7.6, 10), "1C")
+    sotf = orc.ir2fr(orc.gaussian_psf(np.array([7.0]), problems.STEP), (N, N))[0]
+    s = problems.STEP_DEG
+    return N, ax, spec, sotf, s, [(0.0, 0.0), (5 * s, -7 * s), (-9 * s, 4 * s)]
+
+
+def test_mrs_blurred_data_to_img_oracle_vs_reference():
+    """``MRSBlurred.data_to_img`` (spectro_blind_rectangle.py:240-283; live call sites: scripts/simulate_deconvolution_mrs_rectangle.py:193,
+    scripts/deconvolution_mrs_single_wavelength.py:159,194) restated, against the reference's own output.  The mean is compared where
+    some pointing contributes; elsewhere the reference returns uninitialised memory."""
+    g = np.load(os.path.join(G, "mrs_blurred_d2i.npz"))
+    N, ax, spec, sotf, s, pts = d2i_case()
+    bo = orc.BlurredOracle(sotf, ax, ax, spec, s, pts)
+    x = np.random.default_rng(int(g["x_seed"])).random((N, N)) * np.linspace(0.0, 3.0, N)[None, :]
+    assert rel(bo.forward(x), g["y"]) < 1e-13
+    wm, gl = bo.data_to_img(g["y"])
+    assert np.array_equal(gl != 0, g["covered"])                       # the threshold and the column patches cut the same pixels
+    assert rel(gl, g["global_img"]) < 1e-13 and rel(wm, g["weighted_mean"]) < 1e-13
+    assert (gl == 0).sum() > 0 and ((gl != 0) & (wm != gl)).sum() > 0  # uncovered pixels exist, and pixels seen by several pointings
+
+
 def test_model_wct_oracle_vs_reference():
     """WCTOracle against the reference's Model_WCT outputs (tests/golden/model_wct.npz)."""
     import importlib.util

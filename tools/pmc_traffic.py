@@ -33,7 +33,7 @@ def load(dirname, counter):
 
 
 def short(name):
-    for key in ("gemm_nt_f16x2_cc_kernel", "dft_h2_adjmix_kernel", "dft_h2_adjmix_reduce_kernel", "dft_h2_kernel", "dft_rx3_kernel", "dft_fold4_kernel", "dft_fold_kernel", "gemm_f32_kernel<128, 128>", "gemm_f32_kernel<64, 128>", "gemm_f32_kernel<128, 64>",
+    for key in ("gemm_nt_f16x2_cc_kernel", "dft_ct_kernel", "dft_h2_adjmix_kernel", "dft_h2_adjmix_reduce_kernel", "dft_h2_kernel", "dft_rx3_kernel", "dft_fold4_kernel", "dft_fold_kernel", "gemm_f32_kernel<128, 128>", "gemm_f32_kernel<64, 128>", "gemm_f32_kernel<128, 64>",
                 "gemm_f32_kernel<64, 64>", "spmm_group_gather_f16_kernel", "spmm_group_scatter_kernel", "spmm_rows_f16_kernel", "spmm_rows_kernel", "specmix_fwd_ilv_kernel", "specmix_adj_ilv_kernel", "specmix_fwd_kernel", "specmix_adj_kernel",
                 "fill_zero_kernel", "y_from_cpart_kernel", "ymat_from_y_kernel"):
         if key in name:
