@@ -92,6 +92,10 @@ typedef struct {
                                           gather / scatter rows) accumulated in float64 on plain vector kernels.  Same operator,
                                           same fp32 storage, ~100x slower: for the strict dot test
                                           (test/sandbox_dottest.py:16-27 with randn vectors), not for production. */
+    int32_t exact;                     /* production plan without its two approximations (both bounded at plan creation, DESIGN.md
+                                          section 4): bit 0 = every K step of the spectral-blur GEMMs keeps all three fp16
+                                          products (no far class; same as SURFH_WBLUR_FAR=0), bit 1 = the transform passes visit
+                                          the whole spectrum (no OTF-support lists; same as SURFH_OTF_SUPPORT=0).  0 = default. */
 } surfh_config;
 
 const char *surfh_last_error(void);

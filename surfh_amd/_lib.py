@@ -40,6 +40,7 @@ class Config(C.Structure):
         ("templates", c_double_p), ("sotf", c_double_p),
         ("n_channels", C.c_int32), ("channels", C.POINTER(ChannelDesc)),
         ("device", C.c_int32), ("stream", C.c_void_p), ("split_k_forward", C.c_int32), ("verify", C.c_int32),
+        ("exact", C.c_int32),
     ]
 
 

@@ -949,6 +949,7 @@ int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
 // adjoint stays the transpose of the forward.  Nothing is dropped when every tile has such an entry (SURFH_OTF_SUPPORT=0: off).
 int otf_support(surfh_plan *p, const surfh_config *cfg) {
     const bool on = [] { const char *e = getenv("SURFH_OTF_SUPPORT"); return !(e && e[0] == '0'); }();      // read at plan creation
+    if (cfg->exact & 2) return 0;
     if (!on || !cfg->sotf || !p->ilv || p->T < 1 || !p->fuse_mix || p->LP % 128) return 0;
     const int nkb = p->Nb / 2 + 1, nch = (int)(p->LP / 128);
     std::vector<int> bmax(nch, -1), amaxk(nch, -1);   // largest k_beta / folded k_alpha of the support over a chunk's planes (-1: none)
@@ -1848,7 +1849,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             if (dev_upload(&c.bscale, ones)) return bail(1);
             if (launch_split2h(p->stream, c.W, c.W16, nw, nw, c.sW) || launch_split2h(p->stream, c.Wt, c.Wt16, nw, nw, c.sW))
                 return bail(fail("operand split failed"));
-            const bool far_steps = [] { const char *e = getenv("SURFH_WBLUR_FAR"); return !(e && e[0] == '0'); }();      // read at plan creation
+            const bool far_steps = !(cfg->exact & 1) && [] { const char *e = getenv("SURFH_WBLUR_FAR"); return !(e && e[0] == '0'); }();      // read at plan creation
             const double far_tol2 = [] { const char *e = getenv("SURFH_WBLUR_FAR_TOL2"); return std::ldexp(1.0, -(e ? atoi(e) : 10)); }();
             const int segChunks = (c.LinP + 1023) / 1024, KA = (c.Ldet + 31) / 32 * 32;
             if (far_steps && c.K / 32 <= 2048 && c.nbs * segChunks <= 64 && KA / 32 <= 2048) {

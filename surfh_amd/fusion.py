@@ -58,6 +58,9 @@ class QuadCriterion_MRS:
         criterion of every iterate is recorded in ``L_crit_val`` instead."""
         assert isinstance(self.mu_reg, (int, float))       # fusion_CT.py:119
         solver = self.model_spectro.cg if method == "lcg" else self.model_spectro.mmmg     # fusion_CT.py:194-198
+        # the regulariser is state of the plan: select this criterion's for the duration of the solve and put back what was
+        # there, so that two criteria sharing one model (different `gradient`) do not change each other's operator
+        prior_before = self.model_spectro.get_prior() if hasattr(self.model_spectro, "get_prior") else None
         self.model_spectro.set_prior(self.gradient)                                         # fusion_CT.py:141-162
         if isinstance(value_init, (int, float)):
             init = np.ones(self.shape_of_output) * value_init
@@ -93,8 +96,12 @@ class QuadCriterion_MRS:
         else:
             callback = None
         t0 = time.time()
-        x, gn, nit = solver(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
-                            max_iter=maximum_iterations, tol=tolerance, callback=callback)
+        try:
+            x, gn, nit = solver(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
+                                max_iter=maximum_iterations, tol=tolerance, callback=callback)
+        finally:
+            if prior_before is not None:
+                self.model_spectro.set_prior(prior_before)
         last = np.sqrt(gn[-1]) if method == "lcg" else gn[-1]      # lcg traces r.r, mmmg |grad|
         res = OptimizeResult(x=x.ravel(), grad_norm=list(gn), nit=nit,
                              success=bool(last < x.size * tolerance), time=time.time() - t0)
@@ -358,6 +365,14 @@ class DistributedFusion:
         # forward model reads the maps' spectra in the loader of its first transform pass, the adjoint's last pass writes them;
         # no transform of the maps, no padding, no prior kernel inside the iteration).  The basis is orthonormal, so the CG
         # recurrences and r.r are those of the maps.  SURFH_SPECTRAL_CG=0: vectors are the maps.
+        self._agree_basis()
+        self._finish_init(split)
+
+    def _agree_basis(self):
+        """Which basis the solver's vectors live in (the maps, or their scaled half spectra where the operator offers the
+        spectral-domain calls -- which depends on the plan AND on its current regulariser: the joint Laplacian has no spectral
+        form here).  Called at construction and again by ``start``: a ``set_prior`` between two solves must not leave a stale choice."""
+        torch, world = self.torch, self.world
         self.spec = bool(getattr(self.model, "spec_supported", None)) and self.model.spec_supported() and \
             os.environ.get("SURFH_SPECTRAL_CG", "1") != "0"
         if world > 1 or self.force:
@@ -371,6 +386,8 @@ class DistributedFusion:
             nvs = torch.tensor([self.nv, -self.nv], dtype=torch.int64, device=self.dev if torch.distributed.get_backend() == "nccl" else "cpu")
             torch.distributed.all_reduce(nvs, op=torch.distributed.ReduceOp.MAX)
             assert int(nvs[0]) == self.nv and int(nvs[1]) == -self.nv, "ranks disagree on the length of the solver's vectors"
+
+    def _finish_init(self, split):
         self._ytmp = None
         if split == "lambda" and getattr(self, "_band_groups", None):
             idx = np.cumsum([0] + [int(np.prod(c.oshape)) for c in self.model.channels]) if hasattr(self.model, "channels") \
@@ -442,6 +459,7 @@ class DistributedFusion:
     def start(self, y, mu=1.0, mu_reg=0.0, x0=None):
         torch, m = self.torch, self.model
         dev = self.dev
+        self._agree_basis()              # the regulariser may have changed since construction (set_prior)
         self._nosync = hasattr(m, "cg_iter_nosync_dev")          # the HIP operator keeps the CG scalars on the device
         with self._ctx():
             shape = m.ishape

@@ -87,8 +87,10 @@ class spectroSigRLSCT(LinOp):
                  step_degree: float, pointings: Sequence[instru.CoordList], *, device: int = 0,
                  channels: Optional[Sequence[int]] = None, with_ref: bool = True, stream: Optional[int] = None,
                  split_k_forward: int = 0, gridding: str = "bilinear", lam_slices=None, channel_opts: Optional[dict] = None,
-                 verify: bool = False):
-        """``sotf=None`` (plane-wise plans only, ``templates=None``) means no spatial blur; ``channel_opts`` are the
+                 verify: bool = False, exact: int = 0):
+        """``exact``: ``surfh_config.exact`` -- 1: all three fp16 products on every K step of the spectral-blur GEMMs, 2: whole
+        spectrum in the transform passes, 3: both (the production kernels without their two bounded approximations).
+        ``sotf=None`` (plane-wise plans only, ``templates=None``) means no spatial blur; ``channel_opts`` are the
         ``ChannelGeometry`` variants of the slice <-> cube projections (see ``Channel`` below).  ``verify=True`` builds the
         verification plan (include/surfh_amd.h ``surfh_config.verify``): the same operator with every long sum accumulated in
         float64 -- slow; what the strict dot test with zero-mean test vectors runs on."""
@@ -159,6 +161,7 @@ class spectroSigRLSCT(LinOp):
         cfg.stream = C.c_void_p(stream) if stream else None
         cfg.split_k_forward = split_k_forward
         cfg.verify = 1 if verify else 0
+        cfg.exact = int(exact)
         plan = C.c_void_p()
         _lib.check(L.surfh_plan_create(C.byref(cfg), C.byref(plan)), ValueError)
         self._L, self._plan = L, plan
@@ -306,6 +309,11 @@ class spectroSigRLSCT(LinOp):
         if gradient not in ("separated", "joint"):
             raise ValueError(f"gradient must be 'separated' or 'joint', not {gradient!r}")
         _lib.check(self._L.surfh_set_prior(self._plan, 1 if gradient == "joint" else 0))
+        self._prior = gradient
+
+    def get_prior(self) -> str:
+        """The regulariser ``set_prior`` selected last ("separated" on a new model)."""
+        return getattr(self, "_prior", "separated")
 
     # ---- solver on one GPU ------------------------------------------------------------------
     def cg(self, data, mu=1.0, mu_reg=0.0, x0=None, max_iter=10, tol=1e-12, refresh=50, callback=None):

@@ -600,6 +600,34 @@ def test_alternative_kernel_paths_where_they_engage(mid, env, changes_bits):
         assert rg[0] == 0 and rg[1] == cfg["N"]
 
 
+def test_exact_flags_of_the_config(mid):
+    """``surfh_config.exact`` switches the two bounded approximations off per plan, without environment variables: the same
+    bits as SURFH_WBLUR_FAR=0 + SURFH_OTF_SUPPORT=0."""
+    cfg, u, out, ref, st = mid
+    m = build_model(cfg, exact=3)
+    try:
+        ks, otf = [int(v) for v in m.debug_buffer("ksteps")], [int(v) for v in m.debug_buffer("otf")[:2]]
+        y, a = np.asarray(m.forward(cfg["maps"])), np.asarray(m.adjoint(u))
+    finally:
+        m.close()
+    assert ks[1] == 0 and ks[3] == 0 and (otf[0] == 0 or otf[0] == otf[1])
+    assert rel(y, ref["fwd"]) < TOL and rel(a, ref["adj"]) < TOL
+    old = {k: os.environ.get(k) for k in ("SURFH_WBLUR_FAR", "SURFH_OTF_SUPPORT")}
+    os.environ.update(SURFH_WBLUR_FAR="0", SURFH_OTF_SUPPORT="0")
+    try:
+        m2 = build_model(cfg)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k)
+            else:
+                os.environ[k] = v
+    try:
+        assert np.array_equal(np.asarray(m2.forward(cfg["maps"])), y) and np.array_equal(np.asarray(m2.adjoint(u)), a)
+    finally:
+        m2.close()
+
+
 @pytest.mark.parametrize("maker", [problems.config1, problems.two_channel_small, problems.two_channel_disjoint],
                          ids=["config1", "overlapping_windows", "disjoint_windows"])
 def test_adjoint_accumulator_carries_no_state(maker):
