@@ -12,7 +12,9 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 #ifndef CT_EXP
-#define CT_EXP 0        // tools/exp: 2 no stores (and no combine: dead code), 4 no MFMAs, 16 no group synchronisation (wrong results), 32 no loads, 64 workgroup barrier instead of the group counters
+#define CT_EXP 0        // tools/exp: 2 no stores (and no combine: dead code), 4 no MFMAs, 16 no group synchronisation (wrong results), 32 no loads,
+                        // 64 workgroup barrier instead of the group counters, 256 every store into one cache-resident region, 512 the combine without
+                        // its stores, 1024 stores without the twiddle / butterfly arithmetic
 #endif
 
 namespace {
@@ -364,6 +366,7 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
         }
         CT_MFMA(1, nkt - 1, acc2, c1h, c1l);
         if (more) split8h(x1, en, c1h, c1l);
+        float exp_sink = 0.f;
         {
             // ---- epilogue: the R sub-transforms of a group meet in LDS, 16 rows r (and their mirrors M - r) per phase --------
             const int tx = tile % tilesX;
@@ -371,12 +374,12 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
             const float f = __builtin_amdgcn_ldexpf(g.scale, -e - kA);
             // Y_c[r] = C E_c + q S O_other,  Y_c[M - r] = C E_c - q S O_other,  q = sgn * (c ? 1 : -1)
             const float fq = f * g.sgn * sig;
-            float *const dtile = g.dst + bz * g.sC + (long)tx * DST_T;
+            float *const dtile = (CT_EXP & 256) ? g.dst + (long)(tx & 7) * DST_T : g.dst + bz * g.sC + (long)tx * DST_T;
             const float sgs = g.sgn * sig;
             const int nph = (Mh + 15) / 16;
             // row pitch and lane half as values the compiler cannot see through: the per-row addresses below are loop invariants
             // it would otherwise keep in registers across the k loop (measured: 130-240 spilled VGPRs)
-            long ldc_o = g.ldc;
+            long ldc_o = (CT_EXP & 256) ? 64 : g.ldc;         // 256 (tools/exp): every store into one small cache-resident region
             asm volatile("" : "+s"(ldc_o));
             const int he = hv;
             const unsigned ldc4 = (unsigned)ldc_o * 4u;
@@ -386,79 +389,123 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
             const int wrange = (int)(ldc4 + 256u);
             constexpr unsigned VOOB = 0x7FFFFF00u;
             const long kstride = (long)M * ldc_o;
-#pragma unroll
-            for (int ph = 0; ph < 2 * MAXMT; ++ph) {
-                if (ph < nph) {                                    // wave- and workgroup-uniform
-                    const int mt = ph >> 1, q2 = ph & 1;
+            // The phases run as a loop (one copy of the combine in the instruction stream); only the hand-over of the accumulators,
+            // whose registers need static indices, is unrolled per phase.
+#define CT_XWRITE(mt_, q2_)                                                                                     \
+    _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                             \
+        const int slot = (i & 3) + 8 * (i >> 2);       /* + 4 h (in xw) */                                      \
+        const float a1 = acc1[mt_][8 * (q2_) + i], a2 = acc2[mt_][8 * (q2_) + i];                               \
+        xw[slot * 32] = f * a1 + fq * a2;                                                                       \
+        xw[(16 + slot) * 32] = f * a1 - fq * a2;                                                                \
+    }
+#pragma clang loop unroll(disable)
+            for (int ph = 0; ph < nph; ++ph) {
+                {
                     const int buf = phase & 1;
                     ++phase;
                     float *const xw = xbuf + (buf * NW + wave) * XFLOATS + l31 + 128 * he;
-#pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const int slot = (i & 3) + 8 * (i >> 2);       // + 4 h (in xw)
-                        const float a1 = acc1[mt][8 * q2 + i], a2 = acc2[mt][8 * q2 + i];
-                        xw[slot * 32] = f * a1 + fq * a2;
-                        xw[(16 + slot) * 32] = f * a1 - fq * a2;
+                    switch (ph) {
+                        case 0: CT_XWRITE(0, 0) break;
+                        case 1: CT_XWRITE(0, 1) break;
+                        case 2: CT_XWRITE(1, 0) break;
+                        case 3: CT_XWRITE(1, 1) break;
+                        case 4: CT_XWRITE(2, 0) break;
+                        default: CT_XWRITE(2, 1) break;
                     }
                     if (CT_EXP & 64) lds_barrier();
                     else if (!(CT_EXP & 16)) group_arrive_wait(gsync + grp, (unsigned)(R * phase), lane);
                     const float *const xg = xbuf + (buf * NW + grp * R) * XFLOATS + l31 + 32 * he;
+                    // this wave's share of the phase's 8 row pairs: every LDS read of the phase is requested first (row pairs beyond the
+                    // share read pair 7: in range, unused), so that the dependent chains of the pairs overlap
+                    constexpr int NX = (8 + R - 1) / R;
+                    f32x2 yall[NX][R], wpall[NX][R - 1], wmall[NX][R - 1];
 #pragma unroll
-                    for (int xi_ = 0; xi_ < (8 + R - 1) / R; ++xi_) {
-                        const int x = n1 + R * xi_;                // this wave's share of the phase's 8 row pairs
-                        const int r0 = 32 * mt + 16 * q2 + 2 * x;
+                    for (int xi_ = 0; xi_ < NX; ++xi_) {
+                        const int xx = n1 + R * xi_ < 8 ? n1 + R * xi_ : 7;
+                        const int rr = 16 * ph + 2 * xx + he;
+                        const bool okr_ = rr < Mh, okm_ = okr_ && rr >= 1 && 2 * rr != M;
+                        const float *const twp = twl + (okr_ ? rr : 0) * ((R - 1) * 2), *const twm = twl + (okm_ ? M - rr : 0) * ((R - 1) * 2);
+#pragma unroll
+                        for (int n = 0; n < R; ++n) yall[xi_][n] = f32x2{xg[n * XFLOATS + (2 * xx) * 32], xg[n * XFLOATS + (16 + 2 * xx) * 32]};
+#pragma unroll
+                        for (int n = 1; n < R; ++n) {
+                            wpall[xi_][n - 1] = *reinterpret_cast<const f32x2 *>(twp + (n - 1) * 2);
+                            wmall[xi_][n - 1] = *reinterpret_cast<const f32x2 *>(twm + (n - 1) * 2);
+                        }
+                    }
+#pragma unroll
+                    for (int xi_ = 0; xi_ < NX; ++xi_) {
+                        const int x = n1 + R * xi_;
+                        const int r0 = 16 * ph + 2 * x;
                         if (x < 8 && r0 < Mh) {                    // wave-uniform
                             const int r = r0 + he;
                             const bool okr = r < Mh, okm = okr && r >= 1 && 2 * r != M;
                             const int rm = okm ? M - r : 0;
-                            float yp[R], ym[R];
+                            // (row r, mirror row M - r) travel as the two halves of one register pair: every operation below is one
+                            // packed instruction for both (v_pk_mul / v_pk_fma / v_pk_add)
+                            f32x2 y[R];
 #pragma unroll
-                            for (int n = 0; n < R; ++n) {
-                                yp[n] = xg[n * XFLOATS + (2 * x) * 32];
-                                ym[n] = xg[n * XFLOATS + (16 + 2 * x) * 32];
-                            }
+                            for (int n = 0; n < R; ++n) y[n] = yall[xi_][n];
                             // twiddles w_N^{n k2} (table: inverse sign), k2 = r and M - r
-                            const float *const twp = twl + (okr ? r : 0) * ((R - 1) * 2), *const twm = twl + rm * ((R - 1) * 2);
 #pragma unroll
                             for (int n = 1; n < R; ++n) {
-                                const f32x2 wp = *reinterpret_cast<const f32x2 *>(twp + (n - 1) * 2);
-                                const f32x2 wm = *reinterpret_cast<const f32x2 *>(twm + (n - 1) * 2);
-                                yp[n] = wp[0] * yp[n] + sgs * wp[1] * pair_swap(yp[n]);
-                                ym[n] = wm[0] * ym[n] + sgs * wm[1] * pair_swap(ym[n]);
+                                const f32x2 wp = wpall[xi_][n - 1], wm = wmall[xi_][n - 1];
+                                const f32x2 wc = {wp[0], wm[0]}, ws = {sgs * wp[1], sgs * wm[1]};
+                                const f32x2 ysw = {pair_swap(y[n][0]), pair_swap(y[n][1])};
+                                y[n] = wc * y[n] + ws * ysw;
                             }
-                            float yps[R], yms[R];
+                            f32x2 ys[R];
 #pragma unroll
-                            for (int n = 0; n < R; ++n) {
-                                yps[n] = pair_swap(yp[n]);
-                                yms[n] = pair_swap(ym[n]);
-                            }
-                            float Xp[R], Xm[R];                    // X[r + M k1], X[(M - r) + M k1]
+                            for (int n = 1; n < R; ++n) ys[n] = f32x2{pair_swap(y[n][0]), pair_swap(y[n][1])};
+                            f32x2 X[R];                            // (X[r + M k1], X[(M - r) + M k1])
 #pragma unroll
                             for (int k1 = 0; k1 < R; ++k1) {
-                                float sp = yp[0], sm = ym[0];
+                                f32x2 acc = y[0];
 #pragma unroll
                                 for (int n = 1; n < R; ++n) {
                                     const float cr = wr_cos<R>((n * k1) % R), ci = wr_sin<R>((n * k1) % R);
-                                    if (cr != 0.f) { sp += cr * yp[n]; sm += cr * ym[n]; }
-                                    if (ci != 0.f) { sp += (sgs * ci) * yps[n]; sm += (sgs * ci) * yms[n]; }
+                                    if (cr == 1.f) acc += y[n];
+                                    else if (cr == -1.f) acc -= y[n];
+                                    else if (cr != 0.f) acc += cr * y[n];
+                                    if (ci != 0.f) acc += (sgs * ci) * ys[n];
                                 }
-                                Xp[k1] = sp;
-                                Xm[k1] = sm;
+                                X[k1] = acc;
+                            }
+                            float Xp[R], Xm[R];
+#pragma unroll
+                            for (int k1 = 0; k1 < R; ++k1) { Xp[k1] = X[k1][0]; Xm[k1] = X[k1][1]; }
+                            if (CT_EXP & 1024) {        // tools/exp: no twiddles / butterflies, the LDS values go straight out
+#pragma unroll
+                                for (int k1 = 0; k1 < R; ++k1) { Xp[k1] = yall[xi_][k1][0]; Xm[k1] = yall[xi_][k1][1]; }
+                            }
+                            if (CT_EXP & 512) {         // tools/exp: the combine without its stores
+#pragma unroll
+                                for (int k1 = 0; k1 < R; ++k1) exp_sink += Xp[k1] * Xm[k1];
+                                continue;
                             }
                             if (EP == DFT_CT_STORE) {
-                                // rows (r0 + h) + M k1 and (M - r0 - 1 + (1 - h)) + M k1: scalar row base per store, the half in the lane offset
-                                const unsigned vp_ = okr ? vlo : VOOB, vm_ = okm ? vmi : VOOB;
+                                // rows (r0 + h) + M k1 and (M - r0 - 1 + (1 - h)) + M k1: a scalar running pointer per row pair, the half
+                                // in the lane offset.  Interior pairs (both rows and both mirrors exist: all but the pair of row 0, the
+                                // last one and, for even M, the one holding M / 2) store unmasked through global stores on a scalar base;
+                                // the others through a buffer descriptor whose range drops the masked lanes.  A row pair is skipped
+                                // (scalar branch) when both of its rows lie beyond the row limit.
                                 const float *pp_ = dtile + (long)r0 * ldc_o, *pm_ = dtile + (long)(M - r0 - 1) * ldc_o;
+                                const bool inner = r0 >= 1 && r0 + 1 < Mh && 2 * r0 != M && 2 * (r0 + 1) != M;
+                                const unsigned vp_ = okr ? vlo : VOOB, vm_ = okm ? vmi : VOOB;
 #pragma unroll
                                 for (int k1 = 0; k1 < R; ++k1) {
                                     if (!(CT_EXP & 2)) {
-                                        // a row pair is stored if either of its rows is inside the limit (a superset of what is read)
                                         const int kp0 = r0 + M * k1, km0 = M - r0 - 1 + M * k1;        // first rows of the two pairs
                                         const int fp_ = kp0 < N - kp0 - 1 ? kp0 : N - kp0 - 1, fm_ = km0 < N - km0 - 1 ? km0 : N - km0 - 1;
-                                        const __amdgpu_buffer_rsrc_t wp_ = __builtin_amdgcn_make_buffer_rsrc((void *)pp_, 0, wrange, 0x00020000);
-                                        const __amdgpu_buffer_rsrc_t wm_ = __builtin_amdgcn_make_buffer_rsrc((void *)pm_, 0, wrange, 0x00020000);
-                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xp[k1]), wp_, (int)vp_, fp_ <= rlim ? 0 : 0x40000000, 0);
-                                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xm[k1]), wm_, (int)vm_, fm_ <= rlim ? 0 : 0x40000000, 0);
+                                        if (inner) {
+                                            if (fp_ <= rlim) *reinterpret_cast<float *>(reinterpret_cast<char *>(const_cast<float *>(pp_)) + vlo) = Xp[k1];
+                                            if (fm_ <= rlim) *reinterpret_cast<float *>(reinterpret_cast<char *>(const_cast<float *>(pm_)) + vmi) = Xm[k1];
+                                        } else {
+                                            const __amdgpu_buffer_rsrc_t wp_ = __builtin_amdgcn_make_buffer_rsrc((void *)pp_, 0, wrange, 0x00020000);
+                                            const __amdgpu_buffer_rsrc_t wm_ = __builtin_amdgcn_make_buffer_rsrc((void *)pm_, 0, wrange, 0x00020000);
+                                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xp[k1]), wp_, (int)vp_, fp_ <= rlim ? 0 : 0x40000000, 0);
+                                            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(Xm[k1]), wm_, (int)vm_, fm_ <= rlim ? 0 : 0x40000000, 0);
+                                        }
                                     }
                                     pp_ += kstride;
                                     pm_ += kstride;
@@ -489,6 +536,7 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
                 }
             }
         }
+        if ((CT_EXP & 512) && exp_sink == 12345.678f) g.dst[0] = exp_sink;
         if (!more) break;
         e = en;
         tile = next;
