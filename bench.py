@@ -183,7 +183,7 @@ def main_config5(args):
             bytes_launch = 0.5 * Lr * (Nf * 8 + N * N * 4)
             ach = bytes_launch / (dom_ms / dom_cnt * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                    "traffic_source": None, "kernel": "dft_ct_kernel" if any(k.startswith("dft_ct_") for k in dft) else "dft_rx3_kernel",
+                    "traffic_source": None, "kernel": "dft_ct_kernel" if any(k.startswith("dft_ct_") for k in dft) else "dft_h2_kernel",
                     "launches": dom_cnt, "avg_ms": dom_ms / dom_cnt,
                     "note": "per launch: half of a 2-D transform's algorithmic bytes, planes x (N (N/2+1) 8 + N^2 4) / 2; HIP-event times of the "
                             f"{n_all} warm-up step(s)"}
@@ -398,12 +398,6 @@ def main():
                 return "dft_h2_kernel"             # four template instances <KIND, MIX> of one kernel (dft_h2.hip)
             if name.startswith("dft_ct_"):
                 return "dft_ct_kernel"             # template instances <R, loader, epilogue> of one kernel (dft_ct.hip)
-            if name.startswith("dft_rx3_"):
-                return "dft_rx3_kernel"            # four template instances <KIND, MIX> of one kernel (dft_rx3.hip)
-            if name.startswith("dft_fold_cols"):
-                return "dft_fold4_kernel"
-            if name.startswith("dft_fold_rows"):
-                return "dft_fold_kernel"
             if name.startswith("spmm_"):
                 f16 = os.environ.get("SURFH_WBLUR_FP32") != "1"
                 if name == "spmm_gather_fwd" and f16:
@@ -451,9 +445,9 @@ def main():
                                 "against the dense peak of that instruction"}
             else:
                 # FFT-conv stage: a 2-D transform of the owned planes algorithmically moves Lown*(Nf*8 + N^2*4) bytes
-                # (SURVEY.md 8d); a CG step holds two (one per direction), each made of one launch of dft_fold4_kernel
-                # (complex pass) and one of dft_fold_kernel (real pass): half of a transform's bytes per launch.
-                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith(("dft_fold", "dft_rx3", "dft_h2", "dft_ct")) else None
+                # (SURVEY.md 8d); a CG step holds two (one per direction), each made of a complex pass along alpha and a
+                # real <-> complex pass along beta: half of a transform's bytes per launch.
+                bytes_launch = 0.5 * Lown * (Nf * 8 + N * N * 4) if dom.startswith(("dft_h2", "dft_ct")) else None
                 ach = bytes_launch / avg_s / 1e9 if bytes_launch else None
                 roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": traffic, "kernel": dom,
@@ -478,7 +472,7 @@ def main():
         # the HBM-bound half of the path as a whole: everything a step spends on its two 2-D transforms, the OTF product and
         # the wavelength reduction (the DFT passes, the fused adjoint tail or the separate reduction kernel) against the
         # algorithmic bytes of the FFT-conv stage.  Per-stage times of the warm-up steps (every stage bracketed).
-        stage_keys = ("dft_rx3", "dft_fold", "dft_h2", "dft_ct", "specmix_adj", "specmix_fwd")
+        stage_keys = ("dft_h2", "dft_ct", "gemm_dft_rows", "gemm_dft_cols", "specmix_adj", "specmix_fwd")
         dft = [(k, v) for k, v in groups_all.items() if k.startswith(stage_keys)]
         if dft:
             n_l = sum(v[0] for _, v in dft)

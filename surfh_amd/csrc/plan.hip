@@ -31,8 +31,6 @@
 #include <vector>
 
 #include "../../include/surfh_amd.h"
-#include "dft_fold.h"
-#include "dft_rx3.h"
 #include "dft_h2.h"
 #include "dft_ct.h"
 #include "gemm_f32.h"
@@ -151,12 +149,11 @@ struct surfh_plan {
     float *Cma = nullptr, *Sma = nullptr, *Gc = nullptr, *Gs = nullptr, *Cf = nullptr, *Sf = nullptr;
     int MPa = 0, KPa = 0, MPb = 0, KPb = 0;
     int n_cu = 256;
-    int rx3_packed = 1;                          // complex DFT passes: both output components in one read of the tile
     bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
     bool gemm_grouped = true;                    // the adjoint's spectral-blur GEMMs of up to four channels as one launch (SURFH_GEMM_GROUPED=0: one each)
     bool scatter_grouped = true;                 // adjoint scatter with SCATTER_G neighbouring pixels per workgroup (GroupTable)
     bool gather_grouped = true;                  // forward gather (fp16 output) likewise
-    bool dense_dft = false, fuse_mix = true, wblur_fp32 = false, rx3 = false;
+    bool dense_dft = false, fuse_mix = true, wblur_fp32 = false;
     // surfh_config.verify: every long sum accumulated in float64 (dense DFT products, spectral blur, adjoint spectral mix,
     // gather / scatter rows) -- the strict dot test; storage stays fp32
     bool verify = false;
@@ -169,6 +166,10 @@ struct surfh_plan {
     // interleaved layout.  ilv = h2 || ct is the layout flag of the complex arrays.
     bool ct = false, ilv = false;
     DftCtPlan ctA, ctB;                          // transform lengths Na / Nb (ctB aliases ctA when they are equal)
+    // which kernel transforms an axis: the choice is per axis (a 300 x 64 image runs dft_ct along alpha and dft_h2 along beta);
+    // h2 = both axes on dft_h2 (fused adjoint tail, OTF-support lists), ct = at least one axis on dft_ct.  An axis neither covers
+    // (a prime factor above 190, fewer than 32 points) puts the plan on the dense fp32 products with planar arrays.
+    int ax_a = 0, ax_b = 0;                      // 0: none, 1: dft_h2, 2: dft_ct
     // cube columns alpha in [a_lo, a_hi) hold every pixel any channel's tables touch: the transform passes that are batched
     // over alpha skip the rest (forward: the cube outside is never read; adjoint: it is zero).  ycol_adj: the adjoint's
     // intermediate in its own buffer, whose columns outside the range stay zero from plan creation on.
@@ -192,8 +193,6 @@ struct surfh_plan {
     int *otf_tabs = nullptr;
     float *ycol_mix = nullptr;
     int h2kA[3] = {0, 0, 0};
-    unsigned short *dft3 = nullptr;              // the six folded matrices split into 3 bf16 planes each (dft_rx3.h)
-    const unsigned short *Cma3 = nullptr, *Sma3 = nullptr, *Gc3 = nullptr, *Gs3 = nullptr, *Cf3 = nullptr, *Sf3 = nullptr;
     float *io_x = nullptr, *io_y = nullptr, *io_cube = nullptr, *hth = nullptr, *mhat2 = nullptr;
     // accumulator of the exact adjoint: cleared ONCE at plan creation.  Every scatter row knows which of its wavelengths an
     // earlier channel has already written in the same pass (read-modify-write) and stores the others, so nothing stale
@@ -871,70 +870,6 @@ int irfft2_lam(surfh_plan *p, const float *src, float *dst) {
     return 0;
 }
 
-// ---- the same two transforms with the symmetry-folded kernel (dft_fold.h): 3x fewer flops --------
-// ---- split-bf16, register-direct variant of the folded passes (dft_rx3.h) ------------------------
-int rfft2_lam_rx3(surfh_plan *p, const float *src, float *dst) {
-    const long LP = p->LP;
-    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
-    DftRx3Args g;   // r2c along beta
-    g.A[0] = p->Cf3; g.A[1] = p->Sf3; g.planeA = (long)p->MPb * p->KPb; g.lda = p->KPb;
-    g.src[0] = src; g.src[1] = src; g.ldb = p->NAP * LP; g.fold[0] = 1.f; g.fold[1] = -1.f; g.Kn = p->Nb;
-    g.dst[0] = p->ycol; g.dst[1] = p->ycol + (long)p->KBP * p->NAP * LP; g.ldc = p->NAP * LP;
-    g.mode = 1; g.e00 = 1.f; g.e11 = -1.f; g.rvalid = hb;
-    g.MP = p->MPb; g.KP = p->KPb; g.N = (int)(p->Na * LP);
-    {
-        Prof pr(p, "dft_rx3_rows_fwd");
-        LAUNCH_OK(launch_dft_rx3(p->stream, g));
-    }
-    {   // c2c along alpha, batched over k_beta; both output components of a tile back to back (second read from cache)
-        DftRx3Args h;
-        h.planeA = (long)p->MPa * p->KPa; h.lda = p->KPa;
-        h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->KBP * p->NAP * LP; h.ldb = LP; h.sB = p->NAP * LP;
-        h.Kn = p->Na; h.ldc = p->KBP * LP; h.sC = LP; h.mode = 0; h.Rn = p->Na; h.rvalid = ha;
-        h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
-        h.A[0] = p->Cma3; h.A[1] = p->Sma3; h.fold[0] = 1.f; h.fold[1] = -1.f; h.dst[0] = dst;
-        h.e00 = 1.f; h.e01 = 1.f; h.e10 = 1.f; h.e11 = -1.f;
-        h.nvar = 2; h.packed = p->rx3_packed;
-        h.A_alt[0] = p->Sma3; h.A_alt[1] = p->Cma3; h.fold_alt[0] = -1.f; h.fold_alt[1] = 1.f; h.dst_alt = dst + p->PL * LP;
-        h.e_alt[0] = -1.f; h.e_alt[1] = 1.f; h.e_alt[2] = 1.f; h.e_alt[3] = 1.f;
-        Prof pr(p, "dft_rx3_cols_fwd");
-        LAUNCH_OK(launch_dft_rx3(p->stream, h));
-    }
-    return 0;
-}
-
-int irfft2_lam_rx3(surfh_plan *p, const float *src, float *dst, bool mix) {
-    const long LP = p->LP;
-    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
-    {   // c2c along alpha (optionally with the spectral mix formed in the loader), both components per tile
-        DftRx3Args g;
-        g.planeA = (long)p->MPa * p->KPa; g.lda = p->KPa;
-        g.src[0] = src; g.src[1] = src + p->PL * LP; g.ldb = p->KBP * LP;
-        g.Kn = p->Na; g.ldc = p->KBP * LP; g.mode = 0; g.Rn = p->Na; g.rvalid = ha;
-        g.MP = p->MPa; g.KP = p->KPa; g.N = (int)(hb * LP);
-        g.A[0] = p->Cma3; g.A[1] = p->Sma3; g.fold[0] = 1.f; g.fold[1] = -1.f; g.dst[0] = p->ycol;
-        g.e00 = 1.f; g.e01 = -1.f; g.e10 = 1.f; g.e11 = 1.f;
-        g.nvar = 2; g.packed = p->rx3_packed;
-        g.A_alt[0] = p->Sma3; g.A_alt[1] = p->Cma3; g.fold_alt[0] = -1.f; g.fold_alt[1] = 1.f;
-        g.dst_alt = p->ycol + (long)p->NAP * p->KBP * LP;
-        g.e_alt[0] = 1.f; g.e_alt[1] = 1.f; g.e_alt[2] = -1.f; g.e_alt[3] = 1.f;
-        if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
-        Prof pr(p, mix ? "dft_rx3_cols_inv_mix" : "dft_rx3_cols_inv");
-        LAUNCH_OK(launch_dft_rx3(p->stream, g));
-    }
-    DftRx3Args h;   // c2r along beta, batched over alpha
-    h.A[0] = p->Gc3; h.A[1] = p->Gs3; h.planeA = (long)p->MPb * p->KPb; h.lda = p->KPb;
-    h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->NAP * p->KBP * LP; h.ldb = LP; h.sB = p->KBP * LP;
-    h.dst[0] = dst; h.ldc = p->NAP * LP; h.sC = LP;
-    h.mode = 0; h.e00 = 1.f; h.e01 = -1.f; h.e10 = 1.f; h.e11 = 1.f; h.Rn = p->Nb; h.rvalid = hb;
-    h.MP = p->MPb; h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
-    {
-        Prof pr(p, "dft_rx3_rows_inv");
-        LAUNCH_OK(launch_dft_rx3(p->stream, h));
-    }
-    return 0;
-}
-
 // ---- two-piece fp16 passes, matrices resident in LDS, interleaved complex arrays (dft_h2.h) --------
 // cube [NBP][NAP][LP] -> spec [KAP][KBP][LP][2]        (tmp ycol viewed as Z[KBP][NAP][LP][2])
 // `madj` != nullptr: the second pass does not store the spectrum but multiplies it by conj(sotf) and reduces it over the
@@ -1010,7 +945,8 @@ int otf_support(surfh_plan *p, const surfh_config *cfg) {
     return 0;
 }
 
-int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = nullptr, bool acols = false) {
+// `which`: bit 0 = the pass along beta, bit 1 = the pass along alpha (plans whose axes run on different kernels call one of each)
+int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = nullptr, bool acols = false, int which = 3) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
     const bool sub = acols && p->ycol_adj && p->a_hi > p->a_lo;
@@ -1022,10 +958,11 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = null
     g.KP = p->KPb; g.N = (int)(na * LP);
     // fused tail with the OTF's support: it reads no k_beta beyond the support of a wavelength chunk, so those rows are not stored
     if (madj && p->otf_vlist && p->ycol_mix && p->otf_tabs) { g.rtab = p->otf_tabs + 2 * (LP / 128); g.tabLP = (int)LP; }
-    {
+    if (which & 1) {
         Prof pr(p, "dft_h2_rows_fwd");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img + 2 * DFT_H2_IMAGE_HALFS, p->h2kA[2]));
     }
+    if (!(which & 2)) return 0;
     DftH2Args h;   // c2c along alpha, batched over k_beta
     h.kind = 0; h.src = yc; h.ldb = 2 * LP; h.sB = 2 * p->NAP * LP; h.Kn = p->Na;
     h.dst = dst; h.ldc = 2 * p->KBP * LP; h.sC = 2 * LP; h.Rn = p->Na; h.rvalid = ha;
@@ -1058,7 +995,7 @@ int rfft2_lam_h2(surfh_plan *p, const float *src, float *dst, float *madj = null
 
 // spec [KAP][KBP][LP][2] -> cube [NBP][NAP][LP]        (tmp ycol viewed as Y[NAP][KBP][LP][2])
 // `acols`: only the cube columns alpha in [a_lo, a_hi) are wanted (the gathers read nothing else)
-int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false) {
+int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false, int which = 3) {
     const long LP = p->LP;
     const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
     DftH2Args g;   // c2c along alpha (optionally with the spectral mix formed in the loader)
@@ -1074,10 +1011,11 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     float *const yc = supp ? p->ycol_mix : p->ycol;
     if (supp) { g.vlist = p->otf_vlist; g.nvalid = p->otf_nvalid; g.dst = yc; }
     if (supp && p->otf_tabs) { g.ktab = p->otf_tabs; g.tabLP = (int)LP; }          // k_alpha beyond the support: not read
-    {
+    if (which & 2) {
         Prof pr(p, mix ? "dft_h2_cols_inv_mix" : "dft_h2_cols_inv");
         LAUNCH_OK(launch_dft_h2(p->stream, g, p->h2img, p->h2kA[0]));
     }
+    if (!(which & 1)) return 0;
     const bool sub = acols && p->a_hi > p->a_lo;
     const int a0 = sub ? p->a_lo : 0, na = sub ? p->a_hi - p->a_lo : p->Na;
     DftH2Args h;   // c2r along beta, batched over alpha: cube[b] = Gc Yr - Gs Yi, cube[N-b] = Gc Yr + Gs Yi
@@ -1096,7 +1034,7 @@ int irfft2_lam_h2(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
 // ---- Cooley-Tukey passes (dft_ct.h): the same four passes for N = R * M, interleaved complex arrays ---------------
 // cube [NBP][NAP][LP] -> spec [KAP][KBP][LP][2]        (tmp ycol viewed as Z[KBP][NAP][LP][2])
 // `lists`: the caller is the adjoint's tail, whose reduction reads the spectrum only inside the OTF's support
-int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false, bool lists = false) {
+int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false, bool lists = false, int which = 3) {
     const long LP = p->LP;
     const int hb = p->Nb / 2 + 1;
     const bool sub = acols && p->ycol_adj && p->a_hi > p->a_lo;
@@ -1111,10 +1049,11 @@ int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false
     // the reduction reads no k_beta beyond the support of a wavelength chunk: those rows are not stored (chunks of 64 packed pairs)
     const bool supp = lists && p->otf_vlist && p->ycol_mix && p->otf_tabs && p->T > 0;
     if (supp) { g.rtab = p->otf_tabs + 2 * (LP / 128); g.tabLP = (int)(LP / 2); g.tabShift = 6; }
-    {
+    if (which & 1) {
         Prof pr(p, "dft_ct_rows_fwd");
         LAUNCH_OK(launch_dft_ct(p->stream, g, p->ctB));
     }
+    if (!(which & 2)) return 0;
     DftCtArgs h;   // c2c along alpha, batched over k_beta
     h.R = p->ctA.R; h.M = p->ctA.M; h.loader = DFT_CT_PLAIN; h.epi = DFT_CT_STORE; h.sgn = -1.f;
     h.scale = (float)(1.0 / std::sqrt((double)p->Na));
@@ -1133,7 +1072,7 @@ int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false
 }
 
 // spec [KAP][KBP][LP][2] -> cube [NBP][NAP][LP]        (tmp ycol viewed as Y[NAP][KBP][LP][2])
-int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false) {
+int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false, int which = 3) {
     const long LP = p->LP;
     const int hb = p->Nb / 2 + 1;
     DftCtArgs g;   // c2c along alpha (optionally with the spectral mix formed in the loader)
@@ -1148,10 +1087,11 @@ int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     const bool supp = mix && p->otf_vlist && p->ycol_mix && p->otf_tabs;
     float *const yc = supp ? p->ycol_mix : p->ycol;
     if (supp) { g.vlist = p->otf_vlist; g.nvalid = p->otf_nvalid; g.dst = yc; g.ktab = p->otf_tabs; g.tabLP = (int)LP; }
-    {
+    if (which & 2) {
         Prof pr(p, mix ? "dft_ct_cols_inv_mix" : "dft_ct_cols_inv");
         LAUNCH_OK(launch_dft_ct(p->stream, g, p->ctA));
     }
+    if (!(which & 1)) return 0;
     const bool sub = acols && p->a_hi > p->a_lo;
     const int a0 = sub ? p->a_lo : 0, na = sub ? p->a_hi - p->a_lo : p->Na;
     DftCtArgs h;   // c2r along beta, batched over alpha: two neighbouring half spectra as one Hermitian-extended complex sequence
@@ -1168,69 +1108,24 @@ int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     return 0;
 }
 
-int rfft2_lam_fold(surfh_plan *p, const float *src, float *dst) {
-    if (p->h2) return rfft2_lam_h2(p, src, dst);
-    if (p->ct) return rfft2_lam_ct(p, src, dst);
-    if (p->rx3) return rfft2_lam_rx3(p, src, dst);
-    const long LP = p->LP;
-    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
-    DftFoldArgs g;   // r2c along beta: Zr[kb] = Cf * fold+(cube), Zi[kb] = -Sf * fold-(cube)
-    g.A[0] = p->Cf; g.A[1] = p->Sf; g.lda = p->KPb;
-    g.src[0] = src; g.src[1] = src; g.ldb = p->NAP * LP; g.fold[0] = 1.f; g.fold[1] = -1.f; g.Kn = p->Nb;
-    g.dst[0] = p->ycol; g.dst[1] = p->ycol + (long)p->KBP * p->NAP * LP; g.ldc = p->NAP * LP;
-    g.mode = 1; g.e00 = 1.f; g.e11 = -1.f; g.rvalid = hb;
-    g.MP = p->MPb; g.KP = p->KPb; g.N = (int)(p->Na * LP);
-    {
-        Prof pr(p, "dft_fold_rows_fwd");
-        LAUNCH_OK(launch_dft_fold(p->stream, g));
-    }
-    {   // c2c along alpha, all four folded products in one workgroup, batched over k_beta
-        DftFold4Args h;
-        h.Cm = p->Cma; h.Sm = p->Sma; h.lda = p->KPa;
-        h.src_r = p->ycol; h.src_i = p->ycol + (long)p->KBP * p->NAP * LP; h.ldb = LP; h.sB = p->NAP * LP;
-        h.dst_r = dst; h.dst_i = dst + p->PL * LP; h.ldc = p->KBP * LP; h.sC = LP;
-        h.sgn = -1.f; h.Nn = p->Na; h.rvalid = ha; h.MP = p->MPa; h.KP = p->KPa; h.N = (int)LP; h.batch = hb;
-        Prof pr(p, "dft_fold_cols_fwd");
-        LAUNCH_OK(launch_dft_fold4(p->stream, h));
-    }
-    return 0;
+// the two transforms on interleaved arrays, each pass on the kernel of its axis (surfh_plan::ax_a / ax_b)
+int rfft2_lam_ilv(surfh_plan *p, const float *src, float *dst, float *madj = nullptr, bool acols = false, bool lists = false) {
+    if (p->h2) return rfft2_lam_h2(p, src, dst, madj, acols);
+    if (p->ax_b == 1 ? rfft2_lam_h2(p, src, dst, nullptr, acols, 1) : rfft2_lam_ct(p, src, dst, acols, lists, 1)) return 1;
+    return p->ax_a == 1 ? rfft2_lam_h2(p, src, dst, nullptr, acols, 2) : rfft2_lam_ct(p, src, dst, acols, lists, 2);
 }
-
-int irfft2_lam_fold(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
+int irfft2_lam_ilv(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
     if (p->h2) return irfft2_lam_h2(p, src, dst, mix, acols);
-    if (p->ct) return irfft2_lam_ct(p, src, dst, mix, acols);
-    if (p->rx3) return irfft2_lam_rx3(p, src, dst, mix);
-    const long LP = p->LP;
-    const int ha = p->Na / 2 + 1, hb = p->Nb / 2 + 1;
-    {   // c2c along alpha; with `mix` the source spectrum is formed on the fly as sotf * sum_t tpl * mhat
-        DftFold4Args g;
-        g.Cm = p->Cma; g.Sm = p->Sma; g.lda = p->KPa;
-        g.src_r = src; g.src_i = src + p->PL * LP; g.ldb = p->KBP * LP;
-        g.dst_r = p->ycol; g.dst_i = p->ycol + (long)p->NAP * p->KBP * LP; g.ldc = p->KBP * LP;
-        g.sgn = 1.f; g.Nn = p->Na; g.rvalid = ha; g.MP = p->MPa; g.KP = p->KPa; g.N = (int)(hb * LP);
-        if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = p->LP; g.PL = p->PL; g.KBP = p->KBP; }
-        Prof pr(p, mix ? "dft_fold_cols_inv_mix" : "dft_fold_cols_inv");
-        LAUNCH_OK(launch_dft_fold4(p->stream, g));
-    }
-    DftFoldArgs h;   // c2r along beta, batched over alpha: cube[b] = Gc*Yr - Gs*Yi, cube[N-b] = Gc*Yr + Gs*Yi
-    h.A[0] = p->Gc; h.A[1] = p->Gs; h.lda = p->KPb;
-    h.src[0] = p->ycol; h.src[1] = p->ycol + (long)p->NAP * p->KBP * LP; h.ldb = LP; h.sB = p->KBP * LP;
-    h.dst[0] = dst; h.ldc = p->NAP * LP; h.sC = LP;
-    h.mode = 0; h.e00 = 1.f; h.e01 = -1.f; h.e10 = 1.f; h.e11 = 1.f; h.Rn = p->Nb; h.rvalid = hb;
-    h.MP = p->MPb; h.KP = p->KPb; h.N = (int)LP; h.batch = p->Na;
-    {
-        Prof pr(p, "dft_fold_rows_inv");
-        LAUNCH_OK(launch_dft_fold(p->stream, h));
-    }
-    return 0;
+    if (p->ax_a == 1 ? irfft2_lam_h2(p, src, dst, mix, acols, 2) : irfft2_lam_ct(p, src, dst, mix, acols, 2)) return 1;
+    return p->ax_b == 1 ? irfft2_lam_h2(p, src, dst, mix, acols, 1) : irfft2_lam_ct(p, src, dst, mix, acols, 1);
 }
 
 // ---------------------------------------------------------------------------------------------
 // pipelines on device buffers
 // ---------------------------------------------------------------------------------------------
-int rfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? rfft2_lam(p, src, dst) : rfft2_lam_fold(p, src, dst); }
+int rfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? rfft2_lam(p, src, dst) : rfft2_lam_ilv(p, src, dst); }
 int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
-    return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_fold(p, src, dst, mix, acols);
+    return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_ilv(p, src, dst, mix, acols);
 }
 
 // mhat[t] = sum_l tpl[t][l] conj(sotf[l]) rfft2(cube[l])  (T > 0), or the per-plane product (T == 0)
@@ -1238,7 +1133,7 @@ int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, b
 int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
     if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->spec_out ? p->spec_out : p->mhat, acols);
     if (p->ct && !p->dense_dft) {
-        if (rfft2_lam_ct(p, cube, p->spec, acols, true)) return 1;
+        if (rfft2_lam_ilv(p, cube, p->spec, nullptr, acols, true)) return 1;
         SpecmixAdjOpt o;
         o.Na = p->Na; o.KBP = p->KBP;
         if (p->T > 0 && p->otf_vlist && p->ycol_mix && p->otf_tabs) o.lim = p->otf_tabs + 2 * (p->LP / 128);
@@ -1277,7 +1172,7 @@ int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false)
         }
         if (rfft2_cube(p, p->cube, p->mhat)) return 1;
     }
-    if (p->T > 0 && p->fuse_mix && !p->dense_dft && !(p->rx3 && p->T > 4)) {
+    if (p->T > 0 && p->T <= 4 && p->fuse_mix && !p->dense_dft) {
         // spectral mix x OTF fused into the loader of the first inverse pass: `spec` is never written
         // (the normal operator needs the blurred cube only where a gather reads it)
         if (irfft2_cube(p, p->sotf, p->cube, true, hand_over)) return 1;
@@ -1529,9 +1424,9 @@ int surfh_plan_destroy(surfh_plan *p) {
     for (float *v : {p->sotf, p->tpl, p->mhat, p->spec, p->ycol, p->cube, p->ycol_maps, p->maps_pad, p->Fi, p->Gi, p->Gf,
                      p->Ff, p->GiT, p->GfT, p->Cma, p->Sma, p->Gc, p->Gs, p->Cf, p->Sf, p->io_cube, p->hth, p->mhat2, p->gcube, p->io_x, p->io_y, p->cg_x, p->cg_r, p->cg_d, p->cg_q, p->cg_b, p->cg_y, p->cg_qm, p->cg_dd})
         hipFree(v);
-    hipFree(p->dft3);
     hipFree(p->h2img);
     if (p->ctB.img != p->ctA.img) dft_ct_plan_destroy(&p->ctB);
+    else p->ctB = DftCtPlan();
     dft_ct_plan_destroy(&p->ctA);
     hipFree(p->adjmix_part);
     hipFree(p->otf_vlist);
@@ -1647,13 +1542,22 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
 
     {   // which transform kernels run decides the layout of the complex arrays: two-piece fp16 passes (default where
         // the matrices fit LDS) keep them interleaved
-        const char *eh = getenv("SURFH_DFT_H2"), *er = getenv("SURFH_DFT_RX3"), *ed = getenv("SURFH_DFT_DENSE");
-        p->h2 = !cfg->verify && !(eh && eh[0] == '0') && !(er && er[0] == '0') && !(ed && ed[0] == '1') &&
-                dft_h2_supported(p->Na, p->Nb, p->NAP, p->KBP, p->LP);
-        const char *ec = getenv("SURFH_DFT_CT");
-        p->ct = !p->h2 && !cfg->verify && !(ec && ec[0] == '0') && !(er && er[0] == '0') && !(ed && ed[0] == '1') && p->LP % 128 == 0 &&
-                dft_ct_supported(p->Na, p->Nb);
-        p->ilv = p->h2 || p->ct;
+        // the matrices fit LDS) keep them interleaved.  The kernel is chosen per axis: dft_h2 (16 < n/2+1 <= 128, row offsets below
+        // 4 GB), else dft_ct (n = R M), else none -- then the whole plan runs the dense fp32 products on planar arrays.
+        // SURFH_DFT_H2=0 / SURFH_DFT_CT=0 take a kernel out of the choice (A/B), SURFH_DFT_DENSE=1 forces the dense products.
+        const char *eh = getenv("SURFH_DFT_H2"), *ec = getenv("SURFH_DFT_CT"), *ed = getenv("SURFH_DFT_DENSE");
+        const bool h2_on = !(eh && eh[0] == '0'), ct_on = !(ec && ec[0] == '0');
+        auto axis = [&](int n) {
+            if (h2_on && dft_h2_supported(n, n, p->NAP, p->KBP, p->LP)) return 1;
+            if (ct_on && dft_ct_factor(n, nullptr, nullptr)) return 2;
+            return 0;
+        };
+        p->ax_a = axis(p->Na);
+        p->ax_b = axis(p->Nb);
+        p->ilv = !cfg->verify && !(ed && ed[0] == '1') && p->LP % 128 == 0 && p->ax_a && p->ax_b;
+        if (!p->ilv) p->ax_a = p->ax_b = 0;
+        p->h2 = p->ilv && p->ax_a == 1 && p->ax_b == 1;
+        p->ct = p->ilv && !p->h2;
     }
     // ---- constants ------------------------------------------------------------------------
     {   // sotf [Lc][Na][Nb/2+1] complex128  ->  [2][KAP][KBP][LP] float (h2: [KAP][KBP][LP][2]), wavelength innermost
@@ -1715,8 +1619,6 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         const char *e7 = getenv("SURFH_OVERLAP");
         p->overlap = e7 && e7[0] == '1';
         if (p->overlap && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
-        const char *e8 = getenv("SURFH_DFT_PACKED");
-        p->rx3_packed = (e8 && e8[0] == '0') ? 0 : 1;
         const char *e15 = getenv("SURFH_GATHER_GROUPED");
         p->gather_grouped = !(e15 && e15[0] == '0');
         { const char *eg = getenv("SURFH_GEMM_GROUPED"); p->gemm_grouped = !(eg && eg[0] == '0'); }
@@ -1756,13 +1658,17 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
             p->wblur_fp32 = true;
             p->overlap = false;
         }
-        if (p->h2) {   // LDS images of the three matrix pairs (dft_h2.h)
-            if (p->MPa != 128 || p->MPb != 128) return bail(fail("internal: dft_h2 needs 128-row folded matrices"));
-            std::vector<unsigned short> im(3 * DFT_H2_IMAGE_HALFS);
-            p->h2kA[0] = dft_h2_build_image(Cma.data(), Sma.data(), p->MPa, p->KPa, p->KPa, im.data());
-            p->h2kA[1] = dft_h2_build_image(Gc.data(), Gs.data(), p->MPb, p->KPb, p->KPb, im.data() + DFT_H2_IMAGE_HALFS);
-            p->h2kA[2] = dft_h2_build_image(Cf.data(), Sf.data(), p->MPb, p->KPb, p->KPb, im.data() + 2 * DFT_H2_IMAGE_HALFS);
+        if (p->ax_a == 1 || p->ax_b == 1) {   // LDS images of the matrix pairs of the axes that run on dft_h2 (dft_h2.h)
+            if ((p->ax_a == 1 && p->MPa != 128) || (p->ax_b == 1 && p->MPb != 128)) return bail(fail("internal: dft_h2 needs 128-row folded matrices"));
+            std::vector<unsigned short> im(3 * DFT_H2_IMAGE_HALFS, 0);
+            if (p->ax_a == 1) p->h2kA[0] = dft_h2_build_image(Cma.data(), Sma.data(), p->MPa, p->KPa, p->KPa, im.data());
+            if (p->ax_b == 1) {
+                p->h2kA[1] = dft_h2_build_image(Gc.data(), Gs.data(), p->MPb, p->KPb, p->KPb, im.data() + DFT_H2_IMAGE_HALFS);
+                p->h2kA[2] = dft_h2_build_image(Cf.data(), Sf.data(), p->MPb, p->KPb, p->KPb, im.data() + 2 * DFT_H2_IMAGE_HALFS);
+            }
             if (dev_upload(&p->h2img, im)) return bail(1);
+        }
+        if (p->h2) {
             // fused adjoint tail: the last pass of rfft2 multiplies by conj(sotf) and reduces over the wavelengths itself
             // (needs T <= 4 templates and 127 <= Na <= 255 output rows; SURFH_ADJ_FUSED=0: separate pass + reduction)
             const char *eaf = getenv("SURFH_ADJ_FUSED");
@@ -1772,42 +1678,15 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
                 if (npart && dev_alloc(&p->adjmix_part, npart)) return bail(1);
             }
         }
-        if (p->ct) {   // image + twiddles per transform length (dft_ct.h)
-            if (dft_ct_plan_create(p->Na, &p->ctA)) return bail(fail("dft_ct plan (n_alpha = %d) failed", p->Na));
-            if (p->Nb == p->Na) p->ctB = p->ctA;
-            else if (dft_ct_plan_create(p->Nb, &p->ctB)) return bail(fail("dft_ct plan (n_beta = %d) failed", p->Nb));
-            if (p->T >= 1 && p->T <= 4 && otf_support(p, cfg)) return bail(1);
-        }
-        const char *e5 = getenv("SURFH_DFT_RX3");
-        p->rx3 = !(e5 && e5[0] == '0');           // split-bf16 register-direct passes (default); 0: fp32-MFMA folded passes
-        if (p->rx3 && !dft_rx3_supported(p->Na, p->Nb, p->NAP, p->KBP, p->LP)) p->rx3 = false;   // row pitch x rows beyond 4 GB
-        {   // exact three-way bf16 split of the same matrices: x = h + m + l, |x - (h+m+l)| <= 2^-24 |x|
-            std::vector<unsigned short> all;
-            size_t off[6];
-            const std::vector<float> *mats[6] = {&Cma, &Sma, &Gc, &Gs, &Cf, &Sf};
-            for (int i = 0; i < 6; ++i) {
-                const std::vector<float> &M = *mats[i];
-                off[i] = all.size();
-                all.resize(all.size() + 3 * M.size());
-                unsigned short *o = all.data() + off[i];
-                for (size_t j = 0; j < M.size(); ++j) {
-                    float x = M[j], hh, mm;
-                    uint32_t u;
-                    std::memcpy(&u, &x, 4); u &= 0xFFFF0000u; std::memcpy(&hh, &u, 4);
-                    o[j] = (unsigned short)(u >> 16);
-                    float r = x - hh;
-                    std::memcpy(&u, &r, 4); u &= 0xFFFF0000u; std::memcpy(&mm, &u, 4);
-                    o[M.size() + j] = (unsigned short)(u >> 16);
-                    r -= mm;
-                    std::memcpy(&u, &r, 4);
-                    u += 0x7FFFu + ((u >> 16) & 1u);                       // round the last piece to nearest even
-                    o[2 * M.size() + j] = (unsigned short)(u >> 16);
-                }
+        if (p->ct) {   // image + twiddles per transform length of the axes that run on dft_ct (dft_ct.h)
+            if (p->ax_a == 2 && dft_ct_plan_create(p->Na, &p->ctA)) return bail(fail("dft_ct plan (n_alpha = %d) failed", p->Na));
+            if (p->ax_b == 2) {
+                if (p->ax_a == 2 && p->Nb == p->Na) p->ctB = p->ctA;
+                else if (dft_ct_plan_create(p->Nb, &p->ctB)) return bail(fail("dft_ct plan (n_beta = %d) failed", p->Nb));
             }
-            if (dev_upload(&p->dft3, all)) return bail(1);
-            p->Cma3 = p->dft3 + off[0]; p->Sma3 = p->dft3 + off[1]; p->Gc3 = p->dft3 + off[2];
-            p->Gs3 = p->dft3 + off[3]; p->Cf3 = p->dft3 + off[4]; p->Sf3 = p->dft3 + off[5];
+            if (p->ax_a == 2 && p->ax_b == 2 && p->T >= 1 && p->T <= 4 && otf_support(p, cfg)) return bail(1);      // lists: both axes on dft_ct
         }
+        if (!p->ilv) p->dense_dft = true;        // no fast kernel for one of the axes: dense fp32 products
     }
     // ---- work buffers ---------------------------------------------------------------------
     const size_t nspec = (size_t)2 * p->PL * LP, ncube = (size_t)p->NBP * p->NAP * LP;

@@ -4,8 +4,9 @@ surfh/Models/mixing.py:102-270; kernels: surfh/ToolsDir/jax_utils.py:30-41 dft /
 
 Sizes on both sides of the limits of the two-piece fp16 passes (dft_h2.hip: 16 < N/2+1 <= 128, matrices
 resident in LDS, interleaved complex arrays), of the Cooley-Tukey passes for longer axes (dft_ct.hip: N = R x M with
-R = 2, 3, 4 -- 501 = 3 x 167, 512 = 4 x 128, 302 = 2 x 151, mixed factors on the two axes) and of the split-bf16
-fallback (dft_rx3.hip, planar arrays), even and odd lengths, rectangular images; inputs built to stress the per-column block
+R = 2, 3, 4 -- 501 = 3 x 167, 512 = 4 x 128, 302 = 2 x 151, mixed factors on the two axes, one axis on each kernel: 300 x 64,
+501 x 256) and of the dense fp32 fallback for axes neither covers (257 is prime, 20 too short; planar arrays), even and odd
+lengths, rectangular images; inputs built to stress the per-column block
 exponent of the fp16 split (hot pixels, spectra spanning 30 decades, rows that grow towards the
 centre so that the accumulators are rescaled k-step after k-step).  Tolerances are fp32-level.
 """
@@ -52,7 +53,8 @@ def build(shape, L, T, rng, psf_sigma=None):
 
 
 @pytest.mark.parametrize("shape", [(48, 48), (64, 64), (100, 100), (33, 254), (255, 40), (96, 130), (131, 77), (251, 251), (256, 256), (300, 64),
-                                   (501, 501), (512, 512), (300, 300), (501, 256), (384, 510), (258, 570), (302, 302)])
+                                   (501, 501), (512, 512), (300, 300), (501, 256), (384, 510), (258, 570), (302, 302),
+                                   (257, 64), (20, 48), (255, 501)])
 def test_transforms_vs_numpy(shape):
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])
     L, T = 130, 3

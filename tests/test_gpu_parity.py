@@ -486,13 +486,11 @@ def test_disjoint_wavelength_windows(lmm):
     m.close()
 
 
-@pytest.mark.parametrize("env", [{"SURFH_DFT_RX3": "0"}, {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
-                                 {"SURFH_OVERLAP": "1"}, {"SURFH_DFT_H2": "0", "SURFH_DFT_PACKED": "0"}, {"SURFH_DFT_H2": "0"},
-                                 {"SURFH_GATHER_SORTED": "0"}, {"SURFH_SCATTER_RMW_ALL": "1"}, {"SURFH_SCATTER_GROUPED": "0"},
-                                 {"SURFH_GATHER_GROUPED": "0"}, {"SURFH_ADJ_CLEAR": "1"}],
-                         ids=["fold_fp32", "dense_dft", "unfused_mix", "wblur_fp32", "two_streams", "dft_bf16_two_pass_complex",
-                              "dft_bf16_three_piece", "gather_rows_unsorted", "scatter_rmw_everywhere", "scatter_row_by_row",
-                              "gather_row_by_row", "adjoint_clears_accumulator"])
+@pytest.mark.parametrize("env", [{"SURFH_DFT_H2": "0"}, {"SURFH_DFT_DENSE": "1"}, {"SURFH_NO_FUSED_MIX": "1"}, {"SURFH_WBLUR_FP32": "1"},
+                                 {"SURFH_OVERLAP": "1"}, {"SURFH_GATHER_SORTED": "0"}, {"SURFH_SCATTER_RMW_ALL": "1"},
+                                 {"SURFH_SCATTER_GROUPED": "0"}, {"SURFH_GATHER_GROUPED": "0"}, {"SURFH_ADJ_CLEAR": "1"}],
+                         ids=["no_fast_transform_kernel", "dense_dft", "unfused_mix", "wblur_fp32", "two_streams", "gather_rows_unsorted",
+                              "scatter_rmw_everywhere", "scatter_row_by_row", "gather_row_by_row", "adjoint_clears_accumulator"])
 def test_alternative_kernel_paths(env):
     """The A/B kernel paths kept behind environment switches (read at plan creation) stay parity-green.  Only the switches that
     change something at config 1 (64 x 64 x 128, one wavelength chunk) are listed here; the ones whose fast side needs N >= 127,
@@ -561,7 +559,7 @@ def test_default_paths_engage_at_mid_size(mid):
                                               ({"SURFH_ADJ_FUSED": "0"}, True), ({"SURFH_ALPHA_RANGE": "0"}, False),
                                               ({"SURFH_GEMM_GROUPED": "0"}, False), ({"SURFH_DFT_H2": "0"}, True)],
                          ids=["gemm_three_products_everywhere", "gemm_adjoint_plain_tiles", "whole_spectrum", "otf_support_lists_only",
-                              "adjoint_tail_separate", "transform_whole_cube", "adjoint_gemms_one_by_one", "dft_bf16_three_piece"])
+                              "adjoint_tail_separate", "transform_whole_cube", "adjoint_gemms_one_by_one", "transforms_on_dft_ct_2x64"])
 def test_alternative_kernel_paths_where_they_engage(mid, env, changes_bits):
     """A/B of the switches whose fast side needs a problem of some size (tests/problems.py two_channel_mid): both sides within
     1e-5 of the float64 oracle; where the two sides run different arithmetic the outputs must differ in their bits (the switch

@@ -4,7 +4,7 @@
 // are double-buffered in LDS, filled by LDS-DMA into an XOR-swizzled image: each A fragment is one conflict-free
 // ds_read_b128.  Workgroups are persistent (two per CU) and pipeline loads / MFMAs / stores across tile seams.
 #include "dft_rx3.h"
-#include "lds_attr.h"
+#include "../../surfh_amd/csrc/lds_attr.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));

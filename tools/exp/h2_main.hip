@@ -8,7 +8,7 @@
 #include <cstring>
 #include <cmath>
 #include <vector>
-#include "../../surfh_amd/csrc/dft_rx3.h"
+#include "dft_rx3.h"
 #include "../../surfh_amd/csrc/dft_h2.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 __global__ void fill_k(float *p, long n, unsigned seed, int mode, long pitch) {

@@ -3,7 +3,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../../surfh_amd/csrc/dft_rx3.h"
+#include "dft_rx3.h"
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("hip error %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
 int main() {
     const int Na = 251, Nb = 251, ha = 126, hb = 126, NAP = 256, NBP = 256, KBP = 128;
