@@ -19,6 +19,8 @@ int launch_specmix_fwd(hipStream_t s, const float *mhat, const float *sotf, cons
 // largest folded k_alpha inside the OTF's support (bins beyond were not written to `spec` and are skipped);  Nb != 0: the output is
 // the solver's Parseval-scaled half spectrum (bins that are their own conjugate x out_self, the others x out_pair) with
 // prior_mu * |D|^2 * prior_src added (surfh_normal_spec_dev; same arithmetic as the fused tail's reduction, dft_h2.h)
+// T == 0 (plane-wise product): prior_src == madj means that `madj` holds, on entry, the spectrum of the vector the normal operator is
+// being applied to; the kernel then writes out_self * conj(H) Y + prior_mu * |D|^2 * that (the quadratic prior folded in).
 struct SpecmixAdjOpt {
     const int *lim = nullptr;
     int Na = 0;
@@ -136,6 +138,14 @@ int launch_dot_planes(hipStream_t s, const float *a, const float *b, int nplanes
 int launch_cg_step_planes(hipStream_t s, float *x, float *r, const float *d, const float *q, int nplanes, long npix, const double *rr,
                           const double *dq, double *rrn, int update_r);
 int launch_cg_dir_planes(hipStream_t s, float *d, const float *r, int nplanes, long npix, const double *rrn, double *rr);
+// the plane-wise CG blocks on wavelength-innermost arrays [Nb rows][NAP][LP] (the cube layout; kernels.hip): per-wavelength
+// scalars are [LP] doubles, `part` a work buffer of pn_part_doubles(LP) doubles
+int launch_pn_prior_dot(hipStream_t s, const float *d, float *q, int Na, int Nb, int NAP, long LP, float mu_reg, double *part, double *out);
+int launch_pn_dot(hipStream_t s, const float *x, const float *y, int Na, int Nb, int NAP, long LP, double *part, double *out);
+int launch_pn_step(hipStream_t s, float *x, float *r, const float *d, const float *q, int Na, int Nb, int NAP, long LP, const double *rr,
+                   const double *dq, double *part, double *rrn, int update_r);
+int launch_pn_dir(hipStream_t s, float *d, const float *r, int Na, int Nb, int NAP, long LP, const double *rrn, const double *rr);
+size_t pn_part_doubles(long LP);
 // 3MG per plane: rr = r.r, mqm = m.Qm, d = r - (r.Qm / m.Qm) m ; then the 2x2 step in [d, m] with the carried images
 int launch_mmmg_dir_planes(hipStream_t s, float *d, const float *r, const float *m, const float *qm, int nplanes, long npix,
                            double *rr, double *mqm);

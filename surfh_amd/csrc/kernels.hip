@@ -222,15 +222,24 @@ __global__ __launch_bounds__(TPB) void specmix_adj_ilv_kernel(const float *__res
     }
 }
 
+// `out` may hold, on entry, the spectrum of the vector the normal operator was applied to (the forward model left it there): with
+// prior_w != 0 the quadratic prior is added in the same pass, out = mu conj(H) Y + prior_w |D(k)|^2 out_old (circular first
+// differences are diagonal in the Fourier domain: |D|^2 = 4 - 2 cos(2 pi ka / Na) - 2 cos(2 pi kb / Nb))
 __global__ __launch_bounds__(TPB) void specmix_adj_plane_ilv_kernel(const float *__restrict__ spec, const float *__restrict__ sotf,
-                                                                    float *__restrict__ out, long PL, int LP) {
+                                                                    float *out, long PL, int LP, float mu, float prior_w, int Na, int Nb, long KBP) {
     const int l2 = (blockIdx.x * TPB + threadIdx.x) * 2;
     if (l2 >= LP) return;
     const long k = blockIdx.y;
     const float4 hh = *reinterpret_cast<const float4 *>(sotf + (k * LP + l2) * 2);
     const float4 y = *reinterpret_cast<const float4 *>(spec + (k * LP + l2) * 2);
-    *reinterpret_cast<float4 *>(out + (k * LP + l2) * 2) =
-        make_float4(hh.x * y.x + hh.y * y.y, hh.x * y.y - hh.y * y.x, hh.z * y.z + hh.w * y.w, hh.z * y.w - hh.w * y.z);
+    float4 v = make_float4(hh.x * y.x + hh.y * y.y, hh.x * y.y - hh.y * y.x, hh.z * y.z + hh.w * y.w, hh.z * y.w - hh.w * y.z);
+    if (prior_w != 0.f) {
+        const int ka = (int)(k / KBP), kb = (int)(k % KBP);
+        const float w = prior_w * (4.f - 2.f * cospif(2.f * (float)ka / (float)Na) - 2.f * cospif(2.f * (float)kb / (float)Nb));
+        const float4 o = *reinterpret_cast<const float4 *>(out + (k * LP + l2) * 2);
+        v = make_float4(mu * v.x + w * o.x, mu * v.y + w * o.y, mu * v.z + w * o.z, mu * v.w + w * o.w);
+    }
+    *reinterpret_cast<float4 *>(out + (k * LP + l2) * 2) = v;
 }
 
 // one workgroup per frequency bin: the T x T Hessian block sum_l tpl tpl' |H|^2
@@ -980,6 +989,93 @@ __global__ __launch_bounds__(TPB) void cg_dir_planes_kernel(float *__restrict__ 
     if (threadIdx.x == 0) rr[blockIdx.x] = rrn[blockIdx.x];
 }
 
+// ---- the same CG blocks on WAVELENGTH-INNERMOST arrays [NB rows beta][NAP][LP] (the plan's cube layout): the plane-wise solver keeps its
+// vectors in the layout the transforms read and write, so an iteration holds no layout transpose.  A thread owns one wavelength
+// and walks a slice of the pixels; the per-wavelength sums are formed in two deterministic stages (PN_SPLIT partial sums each).
+constexpr int PN_SPLIT = 128;
+__device__ __forceinline__ void pn_partial(double s, double *__restrict__ part, long LP, int l) {
+    __shared__ double sm[TPB / 64][64];
+    sm[threadIdx.x >> 6][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        double t = 0.0;
+        for (int w = 0; w < TPB / 64; ++w) t += sm[w][threadIdx.x];
+        part[(long)blockIdx.y * LP + l] = t;
+    }
+}
+// q += mu_reg (Dr^T Dr + Dc^T Dc) d (circular first differences, fusion_CT.py:16-43 / criterion_2D.py:16-43), part = d . q per wavelength
+__global__ __launch_bounds__(TPB) void pn_prior_dot_kernel(const float *__restrict__ d, float *__restrict__ q, int Na, int Nb, int NAP, long LP,
+                                                           float mu_reg, double *__restrict__ part) {
+    const int l = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const long npix = (long)Na * Nb, p0 = npix * blockIdx.y / gridDim.y, p1 = npix * (blockIdx.y + 1) / gridDim.y;
+    double s = 0.0;
+    for (long pix = p0 + sub; pix < p1; pix += TPB / 64) {
+        const int b = (int)(pix / Na), a = (int)(pix % Na);
+        const long idx = ((long)b * NAP + a) * LP + l;
+        const float dv = d[idx];
+        float qv = q[idx];
+        if (mu_reg != 0.f) {
+            const int am = a ? a - 1 : Na - 1, ap = a + 1 < Na ? a + 1 : 0, bm = b ? b - 1 : Nb - 1, bp = b + 1 < Nb ? b + 1 : 0;
+            const float lap = (2.f * dv - d[((long)b * NAP + am) * LP + l] - d[((long)b * NAP + ap) * LP + l]) +
+                              (2.f * dv - d[((long)bm * NAP + a) * LP + l] - d[((long)bp * NAP + a) * LP + l]);
+            qv += mu_reg * lap;
+            q[idx] = qv;
+        }
+        s += (double)dv * (double)qv;
+    }
+    pn_partial(s, part, LP, l);
+}
+__global__ __launch_bounds__(TPB) void pn_dot_kernel(const float *__restrict__ x, const float *__restrict__ y, int Na, int Nb, int NAP, long LP,
+                                                     double *__restrict__ part) {
+    const int l = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const long npix = (long)Na * Nb, p0 = npix * blockIdx.y / gridDim.y, p1 = npix * (blockIdx.y + 1) / gridDim.y;
+    double s = 0.0;
+    for (long pix = p0 + sub; pix < p1; pix += TPB / 64) {
+        const long idx = ((long)(pix / Na) * NAP + pix % Na) * LP + l;
+        s += (double)x[idx] * (double)y[idx];
+    }
+    pn_partial(s, part, LP, l);
+}
+__global__ __launch_bounds__(TPB) void pn_reduce_kernel(const double *__restrict__ part, int S, long LP, double *__restrict__ out) {
+    const long l = (long)blockIdx.x * TPB + threadIdx.x;
+    if (l >= LP) return;
+    double t = 0.0;
+    for (int k = 0; k < S; ++k) t += part[(long)k * LP + l];
+    out[l] = t;
+}
+// x += s d ; (update_r) r -= s q, part = r . r      with s = rr / dq of the wavelength
+__global__ __launch_bounds__(TPB) void pn_step_kernel(float *__restrict__ x, float *__restrict__ r, const float *__restrict__ d, const float *__restrict__ q,
+                                                      int Na, int Nb, int NAP, long LP, const double *__restrict__ rr, const double *__restrict__ dq,
+                                                      double *__restrict__ part, int update_r) {
+    const int l = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const long npix = (long)Na * Nb, p0 = npix * blockIdx.y / gridDim.y, p1 = npix * (blockIdx.y + 1) / gridDim.y;
+    const double den = dq[l];
+    const float step = den != 0.0 ? (float)(rr[l] / den) : 0.f;
+    double s = 0.0;
+    for (long pix = p0 + sub; pix < p1; pix += TPB / 64) {
+        const long idx = ((long)(pix / Na) * NAP + pix % Na) * LP + l;
+        x[idx] += step * d[idx];
+        if (update_r) {
+            const float rn = r[idx] - step * q[idx];
+            r[idx] = rn;
+            s += (double)rn * (double)rn;
+        }
+    }
+    if (update_r) pn_partial(s, part, LP, l);
+}
+// d = r + (rr' / rr) d per wavelength
+__global__ __launch_bounds__(TPB) void pn_dir_kernel(float *__restrict__ d, const float *__restrict__ r, int Na, int Nb, int NAP, long LP,
+                                                     const double *__restrict__ rrn, const double *__restrict__ rr) {
+    const int l = blockIdx.x * 64 + (threadIdx.x & 63), sub = threadIdx.x >> 6;
+    const long npix = (long)Na * Nb, p0 = npix * blockIdx.y / gridDim.y, p1 = npix * (blockIdx.y + 1) / gridDim.y;
+    const double old = rr[l];
+    const float beta = old != 0.0 ? (float)(rrn[l] / old) : 0.f;
+    for (long pix = p0 + sub; pix < p1; pix += TPB / 64) {
+        const long idx = ((long)(pix / Na) * NAP + pix % Na) * LP + l;
+        d[idx] = r[idx] + beta * d[idx];
+    }
+}
+
 // ---- 3MG on a batch of independent planes (the 2-D deconvolution drivers select it: deconvolution_mrs_noRotation.py:199-212).
 // Same two-step scheme as surfh_mmmg, every plane with its own scalars, one workgroup per plane.
 template <int N>
@@ -1086,11 +1182,13 @@ int launch_specmix_adj(hipStream_t s, const float *spec, const float *sotf, cons
                        long PL, int LP, bool f64, int ilv, const SpecmixAdjOpt *opt) {
     if (T > MAXT) return (int)hipErrorInvalidValue;
     const SpecmixAdjOpt o = opt ? *opt : SpecmixAdjOpt();
-    if (opt && (!ilv || T == 0 || (o.lim && LP % 128) || ((o.lim || o.Nb) && (o.KBP < 1 || o.Na < 1)))) return (int)hipErrorInvalidValue;
+    if (opt && T == 0 && (!ilv || o.lim || (o.prior_src && (o.prior_src != madj || o.KBP < 1 || o.Na < 1 || o.Nb < 1)))) return (int)hipErrorInvalidValue;
+    if (opt && T != 0 && (!ilv || (o.lim && LP % 128) || ((o.lim || o.Nb) && (o.KBP < 1 || o.Na < 1)))) return (int)hipErrorInvalidValue;
     if (ilv) {
         if (T == 0) {
             dim3 grid((LP / 2 + TPB - 1) / TPB, (unsigned)PL);
-            hipLaunchKernelGGL(specmix_adj_plane_ilv_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP);
+            hipLaunchKernelGGL(specmix_adj_plane_ilv_kernel, grid, dim3(TPB), 0, s, spec, sotf, madj, PL, LP, o.out_self, o.prior_src ? o.prior_mu : 0.f,
+                               o.Na, o.Nb, o.KBP);
         } else if (f64) hipLaunchKernelGGL(specmix_adj_ilv_kernel<double>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP, o);
         else hipLaunchKernelGGL(specmix_adj_ilv_kernel<float>, dim3((unsigned)PL), dim3(TPB), 0, s, spec, sotf, tpl, madj, T, PL, LP, o);
         return (int)hipGetLastError();
@@ -1377,6 +1475,33 @@ int launch_mmmg_step_planes(hipStream_t s, float *x, float *r, const float *d, f
     hipLaunchKernelGGL(mmmg_step_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, x, r, d, m, qm, qd, npix, mqm, update_r);
     return (int)hipGetLastError();
 }
+
+// the wavelength-innermost forms: part = work buffer of PN_SPLIT * LP doubles, out / rr / dq / rrn = [LP] doubles
+int launch_pn_prior_dot(hipStream_t s, const float *d, float *q, int Na, int Nb, int NAP, long LP, float mu_reg, double *part, double *out) {
+    if (LP % 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pn_prior_dot_kernel, dim3((unsigned)(LP / 64), PN_SPLIT), dim3(TPB), 0, s, d, q, Na, Nb, NAP, LP, mu_reg, part);
+    hipLaunchKernelGGL(pn_reduce_kernel, dim3((unsigned)((LP + TPB - 1) / TPB)), dim3(TPB), 0, s, part, PN_SPLIT, LP, out);
+    return (int)hipGetLastError();
+}
+int launch_pn_dot(hipStream_t s, const float *x, const float *y, int Na, int Nb, int NAP, long LP, double *part, double *out) {
+    if (LP % 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pn_dot_kernel, dim3((unsigned)(LP / 64), PN_SPLIT), dim3(TPB), 0, s, x, y, Na, Nb, NAP, LP, part);
+    hipLaunchKernelGGL(pn_reduce_kernel, dim3((unsigned)((LP + TPB - 1) / TPB)), dim3(TPB), 0, s, part, PN_SPLIT, LP, out);
+    return (int)hipGetLastError();
+}
+int launch_pn_step(hipStream_t s, float *x, float *r, const float *d, const float *q, int Na, int Nb, int NAP, long LP, const double *rr,
+                   const double *dq, double *part, double *rrn, int update_r) {
+    if (LP % 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pn_step_kernel, dim3((unsigned)(LP / 64), PN_SPLIT), dim3(TPB), 0, s, x, r, d, q, Na, Nb, NAP, LP, rr, dq, part, update_r);
+    if (update_r) hipLaunchKernelGGL(pn_reduce_kernel, dim3((unsigned)((LP + TPB - 1) / TPB)), dim3(TPB), 0, s, part, PN_SPLIT, LP, rrn);
+    return (int)hipGetLastError();
+}
+int launch_pn_dir(hipStream_t s, float *d, const float *r, int Na, int Nb, int NAP, long LP, const double *rrn, const double *rr) {
+    if (LP % 64) return (int)hipErrorInvalidValue;
+    hipLaunchKernelGGL(pn_dir_kernel, dim3((unsigned)(LP / 64), PN_SPLIT), dim3(TPB), 0, s, d, r, Na, Nb, NAP, LP, rrn, rr);
+    return (int)hipGetLastError();
+}
+size_t pn_part_doubles(long LP) { return (size_t)PN_SPLIT * (size_t)LP; }
 
 int launch_cg_dir_planes(hipStream_t s, float *d, const float *r, int nplanes, long npix, const double *rrn, double *rr) {
     hipLaunchKernelGGL(cg_dir_planes_kernel, dim3(nplanes), dim3(TPB), 0, s, d, r, npix, rrn, rr);

@@ -210,6 +210,11 @@ struct surfh_plan {
     float *pl_x = nullptr;
     double pl_mu = 1.0, pl_mu_reg = 0.0;
     int pl_it = 0;
+    // ... with its vectors in the cube's wavelength-innermost layout [NBP][NAP][LP] (no layout transpose inside an iteration):
+    // x, r, d, q, b; per-wavelength scalars [3][LP] + partial sums; set while forward_dev / adjoint_dev are called on such vectors
+    float *pn_v[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double *pn_sc = nullptr, *pn_part = nullptr;
+    bool pn_native = false, pn_active = false, pn_fold_prior = false;
     // profiling
     bool prof = false;
     std::string prof_filter;                     // non-empty: only stages whose name starts with it are bracketed by events
@@ -1142,12 +1147,26 @@ int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
             o.prior_src = p->spec_prior_src; o.prior_mu = p->spec_prior_mu;
         }
         Prof pr(p, "specmix_adj");
+        if (p->T == 0 && p->pn_fold_prior) {      // plane-wise normal operator: mu and the quadratic prior in the OTF product (see below)
+            SpecmixAdjOpt o2;
+            o2.Na = p->Na; o2.Nb = p->Nb; o2.KBP = p->KBP; o2.out_self = (float)p->pl_mu; o2.prior_src = p->mhat; o2.prior_mu = (float)p->pl_mu_reg;
+            LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, 0, p->PL, p->LP, false, 1, &o2));
+            return 0;
+        }
         LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->spec_out ? p->spec_out : p->mhat, p->T, p->PL, p->LP, false, 1,
                                      p->T > 0 ? &o : nullptr));
         return 0;
     }
     if (rfft2_cube(p, cube, p->spec)) return 1;
     Prof pr(p, "specmix_adj");
+    if (p->T == 0 && p->ilv && p->pn_fold_prior) {
+        // plane-wise normal operator: `mhat` still holds the spectrum of the vector the forward half was applied to -- mu and the
+        // quadratic prior go into the OTF product, no prior kernel and no scaling pass afterwards
+        SpecmixAdjOpt o;
+        o.Na = p->Na; o.Nb = p->Nb; o.KBP = p->KBP; o.out_self = (float)p->pl_mu; o.prior_src = p->mhat; o.prior_mu = (float)p->pl_mu_reg;
+        LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, 0, p->PL, p->LP, false, 1, &o));
+        return 0;
+    }
     LAUNCH_OK(launch_specmix_adj(p->stream, p->spec, p->sotf, p->tpl, p->mhat, p->T, p->PL, p->LP, p->verify, p->ilv));
     return 0;
 }
@@ -1164,6 +1183,9 @@ int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false)
             LAUNCH_OK(launch_pad_planes(s, x, p->maps_pad, p->T, p->Na, p->Nb, p->NAP, p->NBP));
         }
         if (rfft2_planes(p, p->maps_pad, p->mhat, p->T)) return 1;
+    } else if (p->pn_native) {
+        // plane-wise solver on wavelength-innermost vectors: x is already in the cube's layout [NBP][NAP][LP]
+        if (rfft2_cube(p, x, p->mhat)) return 1;
     } else {
         {
             Prof pr(p, "cube_transpose");
@@ -1347,6 +1369,8 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
         if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
         Prof pr(p, "unpad_planes");
         LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    } else if (p->pn_native) {
+        if (irfft2_cube(p, p->mhat, x)) return 1;           // straight into the caller's wavelength-innermost vector
     } else {
         if (irfft2_cube(p, p->mhat, p->cube)) return 1;
         const long pl = (long)p->Na * p->Nb;
@@ -1372,7 +1396,7 @@ int normal_dev(surfh_plan *p, const float *d, float *q, double mu) {
     if (adjoint_dev(p, p->cg_y, q, false, ho)) return 1;
     if (mu != 1.0) {
         Prof pr(p, "scale");
-        LAUNCH_OK(launch_scale(p->stream, q, p->isize, (float)mu));
+        LAUNCH_OK(launch_scale(p->stream, q, p->pn_native ? (long)p->NBP * p->NAP * p->LP : p->isize, (float)mu));
     }
     return 0;
 }
@@ -1438,6 +1462,9 @@ int surfh_plan_destroy(surfh_plan *p) {
     hipFree(p->dscratch);
     hipFree(p->cg_hist);
     hipFree(p->pl_sc);
+    for (float *v : p->pn_v) hipFree(v);
+    hipFree(p->pn_sc);
+    hipFree(p->pn_part);
     for (auto &c : p->ch) {
         for (float *v : {c.W, c.Wt, c.Xs, c.Cpart, c.ymat}) hipFree(v);
         hipFree(c.W16);
@@ -2506,14 +2533,72 @@ int surfh_cg_planes(surfh_plan *p, const float *y, double mu, double mu_reg, con
 
 // ---- the same loop with the data and the iterate resident on the device and no host synchronisation inside: begin (b = mu A^T y,
 // r = b - Q x, d = r), any number of step calls, r.r per plane on request.  x_dev stays the caller's buffer and holds the iterate.
+namespace {
+struct PnScope {                       // forward_dev / adjoint_dev read and write wavelength-innermost vectors for the duration of a call
+    surfh_plan *p;
+    explicit PnScope(surfh_plan *pl) : p(pl) { p->pn_native = true; }
+    ~PnScope() { p->pn_native = false; }
+};
+// q = mu A^T A v (+ mu_reg prior, fused with the dot product v . q -> dq) on wavelength-innermost vectors
+int pn_normal(surfh_plan *p, const float *v, float *q, double *dq) {
+    PnScope sc(p);
+    // with interleaved spectra and a prior weight the OTF product of the adjoint applies mu and adds the prior (adjoint_tail): the
+    // two halves are called directly so that no scaling pass follows
+    const bool fold = p->ilv && !p->dense_dft && p->pl_mu_reg != 0.0;
+    if (fold) {
+        p->pn_fold_prior = true;
+        const bool ho = normal_hand_over(p);
+        const int rc = forward_dev(p, v, p->cg_y, ho) || adjoint_dev(p, p->cg_y, q, false, ho);
+        p->pn_fold_prior = false;
+        if (rc) return 1;
+    } else if (normal_dev(p, v, q, p->pl_mu)) {
+        return 1;
+    }
+    Prof pr(p, "pn_prior_dot");
+    if (fold) LAUNCH_OK(launch_pn_dot(p->stream, v, q, p->Na, p->Nb, p->NAP, p->LP, p->pn_part, dq));
+    else LAUNCH_OK(launch_pn_prior_dot(p->stream, v, q, p->Na, p->Nb, p->NAP, p->LP, (float)p->pl_mu_reg, p->pn_part, dq));
+    return 0;
+}
+bool pn_capable(const surfh_plan *p) {
+    const char *e = getenv("SURFH_PLANES_NATIVE");       // 0: vectors in the caller's [Lc][Na][Nb] layout (two transposes per operator application)
+    return !(e && e[0] == '0') && p->T == 0 && p->segs.size() == 1 && p->segs[0].coff == 0 && p->segs[0].start == 0 && p->Lown == p->Lc && p->prior_kind == 0 &&
+           p->LP % 64 == 0;
+}
+}  // namespace
+
 int surfh_cg_planes_begin_dev(surfh_plan *p, const float *y_dev, double mu, double mu_reg, float *x_dev) {
     if (!p || !y_dev || !x_dev) return fail("null argument");
     if (p->T != 0) return fail("surfh_cg_planes is the solver of the plane-wise (no template) model; use surfh_cg with templates");
     if (p->ch.empty()) return fail("plan has no channel");
     HIP_OK(hipSetDevice(p->dev));
-    if (ensure_cg(p)) return 1;
     hipStream_t s = p->stream;
     const int L = p->Lc;
+    p->pn_active = pn_capable(p);
+    if (p->pn_active) {
+        // vectors in the cube's layout: the caller's x is transposed in here and out again at the end of every step call
+        const size_t nc = (size_t)p->NBP * p->NAP * p->LP;
+        for (float *&v : p->pn_v)
+            if (!v) {
+                if (dev_alloc(&v, nc)) return 1;
+                HIP_OK(hipMemsetAsync(v, 0, nc * sizeof(float), s));       // the padding (rows >= Nb, columns >= Na, planes >= Lc) stays zero
+            }
+        if (!p->pn_sc && (dev_alloc(&p->pn_sc, (size_t)3 * p->LP) || dev_alloc(&p->pn_part, pn_part_doubles(p->LP)))) return 1;
+        float *xn = p->pn_v[0], *r = p->pn_v[1], *d = p->pn_v[2], *q = p->pn_v[3], *b = p->pn_v[4];
+        double *rr = p->pn_sc, *dq = p->pn_sc + p->LP;
+        p->pl_x = x_dev; p->pl_mu = mu; p->pl_mu_reg = mu_reg; p->pl_it = 0;
+        LAUNCH_OK(launch_cube_to_lam_inner(s, x_dev, xn, 0, L, p->Na, p->Nb, p->NAP, p->LP));
+        {
+            PnScope sc(p);
+            if (adjoint_dev(p, y_dev, b, false)) return 1;
+        }
+        if (mu != 1.0) LAUNCH_OK(launch_scale(s, b, (long)nc, (float)mu));
+        if (pn_normal(p, xn, q, dq)) return 1;
+        LAUNCH_OK(launch_residual(s, r, b, q, (long)nc));
+        HIP_OK(hipMemcpyAsync(d, r, nc * sizeof(float), hipMemcpyDeviceToDevice, s));
+        LAUNCH_OK(launch_pn_dot(s, r, r, p->Na, p->Nb, p->NAP, p->LP, p->pn_part, rr));
+        return 0;
+    }
+    if (ensure_cg(p)) return 1;
     const long npix = (long)p->Na * p->Nb, n = p->isize;
     if (!p->pl_sc) HIP_OK(hipMalloc((void **)&p->pl_sc, (size_t)3 * L * sizeof(double)));
     p->pl_x = x_dev; p->pl_mu = mu; p->pl_mu_reg = mu_reg; p->pl_it = 0;
@@ -2527,10 +2612,34 @@ int surfh_cg_planes_begin_dev(surfh_plan *p, const float *y_dev, double mu, doub
     return 0;
 }
 int surfh_cg_planes_step_dev(surfh_plan *p, int32_t iters, int32_t refresh) {
-    if (!p || !p->pl_sc || !p->pl_x) return fail("surfh_cg_planes_begin_dev has not been called");
+    if (!p || !p->pl_x || !(p->pn_active ? (void *)p->pn_sc : (void *)p->pl_sc)) return fail("surfh_cg_planes_begin_dev has not been called");
     HIP_OK(hipSetDevice(p->dev));
     hipStream_t s = p->stream;
     const int L = p->Lc;
+    if (p->pn_active) {
+        float *xn = p->pn_v[0], *r = p->pn_v[1], *d = p->pn_v[2], *q = p->pn_v[3], *b = p->pn_v[4];
+        double *rr = p->pn_sc, *dq = p->pn_sc + p->LP, *rrn = p->pn_sc + 2 * p->LP;
+        const long nc = (long)p->NBP * p->NAP * p->LP;
+        for (int i = 0; i < iters; ++i, ++p->pl_it) {
+            if (pn_normal(p, d, q, dq)) return 1;
+            if (refresh > 0 && p->pl_it % refresh == 0) {
+                LAUNCH_OK(launch_pn_step(s, xn, r, d, q, p->Na, p->Nb, p->NAP, p->LP, rr, dq, p->pn_part, rrn, 0));
+                if (pn_normal(p, xn, q, dq)) return 1;
+                LAUNCH_OK(launch_residual(s, r, b, q, nc));
+                LAUNCH_OK(launch_pn_dot(s, r, r, p->Na, p->Nb, p->NAP, p->LP, p->pn_part, rrn));
+            } else {
+                Prof pr(p, "pn_step");
+                LAUNCH_OK(launch_pn_step(s, xn, r, d, q, p->Na, p->Nb, p->NAP, p->LP, rr, dq, p->pn_part, rrn, 1));
+            }
+            {
+                Prof pr(p, "pn_dir");
+                LAUNCH_OK(launch_pn_dir(s, d, r, p->Na, p->Nb, p->NAP, p->LP, rrn, rr));
+            }
+            HIP_OK(hipMemcpyAsync(rr, rrn, (size_t)p->LP * sizeof(double), hipMemcpyDeviceToDevice, s));
+        }
+        LAUNCH_OK(launch_cube_from_lam_inner(s, xn, p->pl_x, 0, L, p->Na, p->Nb, p->NAP, p->LP));      // the caller's iterate
+        return 0;
+    }
     const long npix = (long)p->Na * p->Nb, n = p->isize;
     double *rr = p->pl_sc, *dq = p->pl_sc + L, *rrn = p->pl_sc + 2 * L;
     float *x = p->pl_x;
@@ -2555,9 +2664,9 @@ int surfh_cg_planes_step_dev(surfh_plan *p, int32_t iters, int32_t refresh) {
     return 0;
 }
 int surfh_cg_planes_rr(surfh_plan *p, double *rr_host) {
-    if (!p || !p->pl_sc || !rr_host) return fail("surfh_cg_planes_begin_dev has not been called");
+    if (!p || !rr_host || !(p->pn_active ? p->pn_sc : p->pl_sc)) return fail("surfh_cg_planes_begin_dev has not been called");
     HIP_OK(hipSetDevice(p->dev));
-    HIP_OK(hipMemcpyAsync(rr_host, p->pl_sc, (size_t)p->Lc * sizeof(double), hipMemcpyDeviceToHost, p->stream));
+    HIP_OK(hipMemcpyAsync(rr_host, p->pn_active ? p->pn_sc : p->pl_sc, (size_t)p->Lc * sizeof(double), hipMemcpyDeviceToHost, p->stream));
     HIP_OK(hipStreamSynchronize(p->stream));
     return 0;
 }

@@ -283,6 +283,45 @@ def test_plane_wise_cg_2d_deconvolution():
     m1.close()
 
 
+@pytest.mark.parametrize("native", ["1", "0"], ids=["wavelength_innermost_vectors", "plane_major_vectors"])
+def test_plane_wise_cg_device_resident_loop(native, monkeypatch):
+    """``surfh_cg_planes_begin_dev / _step_dev / _rr`` (what bench.py --config 5 times): data and iterate stay on the device, no
+    host synchronisation inside; the same iterates as ``surfh_cg_planes`` from host buffers, stepped in uneven blocks across a
+    residual refresh.  By default the loop keeps its vectors in the cube's wavelength-innermost layout (no layout transpose inside
+    an iteration, the prior fused into the d.q kernel; sums in another order: fp32-level agreement); SURFH_PLANES_NATIVE=0 runs the
+    kernels of ``surfh_cg_planes`` on the caller's layout (same bits)."""
+    import torch
+    monkeypatch.setenv("SURFH_PLANES_NATIVE", native)
+    L = 6
+    N, bo, m = blurred_case(L=L)
+    try:
+        rng = np.random.default_rng(14)
+        y = bo.forward(rng.random((L, N, N)))
+        y[4] = 0.0
+        mu, mur, nit, refresh = 1.0, 0.05, 9, 4
+        x_ref, gn_ref, n = m.cg(y, mu=mu, mu_reg=mur, x0=None, max_iter=nit, refresh=refresh)
+        dev = torch.device("cuda:0")
+        yt = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32).reshape(-1), device=dev)
+        xt = torch.zeros((L, N, N), dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        m.cg_begin_dev(yt, xt, mu, mur)
+        assert np.allclose(m.cg_rr(), gn_ref[0], rtol=1e-6)
+        for block in (2, 3, 4):
+            m.cg_step_dev(block, refresh)
+        rr = m.cg_rr()
+        x = xt.cpu().numpy()
+        if native == "0":
+            assert np.array_equal(x, np.asarray(x_ref, dtype=np.float32)) and np.array_equal(rr, gn_ref[-1])     # same kernels, same order
+        else:
+            live = [0, 1, 2, 3, 5]
+            e_x, e_r = rel(x[live], x_ref[live]), float(np.max(np.abs(rr[live] - gn_ref[-1][live]) / gn_ref[-1][live]))
+            print(f"plane-wise CG on wavelength-innermost vectors vs plane-major: x {e_x:.1e}, r.r {e_r:.1e}")
+            assert e_x < 1e-4 and e_r < 1e-2
+        assert not x[4].any() and rr[4] == 0.0
+    finally:
+        m.close()
+
+
 def test_slice_cube_projections():
     """the reference's slice <-> cube projections (spectroModelChannel.py:266-336) through
     ``model.channels[k]``, against the golden vectors of the real reference and the oracle."""
