@@ -14,7 +14,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #ifndef CT_EXP
 #define CT_EXP 0        // tools/exp: 2 no stores (and no combine: dead code), 4 no MFMAs, 16 no group synchronisation (wrong results), 32 no loads,
                         // 64 workgroup barrier instead of the group counters, 256 every store into one cache-resident region, 512 the combine without
-                        // its stores, 1024 stores without the twiddle / butterfly arithmetic
+                        // its stores, 1024 stores without the twiddle / butterfly arithmetic, 2048 a third / half of the row pairs not stored
 #endif
 
 namespace {
@@ -477,6 +477,11 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
                             if (CT_EXP & 1024) {        // tools/exp: no twiddles / butterflies, the LDS values go straight out
 #pragma unroll
                                 for (int k1 = 0; k1 < R; ++k1) { Xp[k1] = yall[xi_][k1][0]; Xm[k1] = yall[xi_][k1][1]; }
+                            }
+                            if ((CT_EXP & 2048) && (xi_ & 1)) {     // tools/exp: every other row pair of the wave's share not stored
+#pragma unroll
+                                for (int k1 = 0; k1 < R; ++k1) exp_sink += Xp[k1] * Xm[k1];
+                                continue;
                             }
                             if (CT_EXP & 512) {         // tools/exp: the combine without its stores
 #pragma unroll
