@@ -506,6 +506,30 @@ def main():
                                                           "the spectral response's diagonal, one on its far tails) against the dense fp16 / bf16 MFMA peak",
                                                   "k_steps_near_far_forward_adjoint": [int(v) for v in ks],
                                                   "traffic": pmc.get(gm[0][0], {}).get("hbm_bytes_per_launch")}
+        # The iteration as a whole against SURVEY.md 8d's one-pass-per-stage byte model B_iter (OTF read, blurred cube written / read,
+        # per channel: cube window read, local cube written and read per pointing, W read once, y written / read; per direction;
+        # plus the CG vectors) and its flop count F_iter -- the bound of the path is max(t_HBM, t_MFMA).  The fused gather never
+        # materialises the local cubes the model counts, so the achieved figure is a rate of ALGORITHMIC bytes, not of HBM traffic.
+        try:
+            T = int(m.ishape[0])
+            b_ch = 0.0
+            for c in m.channels:
+                P, S, Ldet, aout = (int(v) for v in c.oshape)
+                Lin = c.wslice.stop - c.wslice.start
+                na, nb = c.local_im_shape
+                b_ch += 4.0 * (Lin * N * N + 2.0 * P * Lin * na * nb + Ldet * Lin * c.slicer.npix_slit_beta_width + P * S * Ldet * aout)
+            b_iter = 2.0 * (Lown * Nf * 8.0 + Lown * N * N * 4.0 + b_ch) + 10.0 * T * N * N * 4.0
+            f_iter = sum(2.0 * 2.0 * np.prod(c.oshape) * (c.wslice.stop - c.wslice.start) * c.slicer.npix_slit_beta_width for c in m.channels)
+            t_hbm, t_f32 = b_iter / (HBM_PEAK_GBS * 1e9), f_iter / (MFMA_F32_PEAK_TF * 1e12)
+            t_it = el / args.steps
+            out["roofline_iteration"] = {"bound": "hbm" if t_hbm >= t_f32 else "mfma", "achieved": b_iter / t_it / 1e9, "peak": HBM_PEAK_GBS,
+                                         "unit": "GB/s", "frac": t_hbm / t_it, "algorithmic_bytes": b_iter, "algorithmic_flops": f_iter,
+                                         "t_hbm_ms": t_hbm * 1e3, "t_mfma_fp32_ms": t_f32 * 1e3, "frac_of_max_bound": max(t_hbm, t_f32) / t_it,
+                                         "note": "SURVEY.md 8d: B_iter at the HBM peak and F_iter at the fp32 matrix-core peak against the measured "
+                                                 "iteration of this rank's units; `frac` = t_HBM / t_iteration; the products run as fp16 splits, so "
+                                                 "the fp32-MFMA time is a reference point, not a bound of this implementation"}
+        except Exception as e:
+            out["roofline_iteration"] = {"error": repr(e)}
         if world == 1:
             # The exported solver -- surfh_cg, what QuadCriterion_MRS.run_method('lcg') and INTEGRATION.md's qmm.lcg replacement
             # run (fusion_CT.py:194-225) -- outside the timed region: two calls of different length from host buffers; the

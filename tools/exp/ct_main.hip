@@ -200,7 +200,7 @@ int main(int argc, char **argv) {
             g.ldc = cs.epi == DFT_CT_HSEP ? 2 * ldx : ldx; g.sC = cs.epi == DFT_CT_HSEP ? ncx * 4 : ncx * 2;
             for (int w = 0; w < 2; ++w) CK(launch_dft_ct(0, g, pl));
             hipEventRecord(e0, 0);
-            const int reps = 5;
+            const int reps = getenv("CT_REPS") ? atoi(getenv("CT_REPS")) : 5;      // CT_REPS=300: sustained load (the clock settles)
             for (int w = 0; w < reps; ++w) CK(launch_dft_ct(0, g, pl));
             hipEventRecord(e1, 0);
             CK(hipDeviceSynchronize());
