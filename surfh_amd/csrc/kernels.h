@@ -124,6 +124,13 @@ int launch_cg_step(hipStream_t s, float *x, float *r, const float *d, const floa
                    const double *dq, double *scratch, double *out_rr);
 // x += step d only (used when the residual is refreshed from scratch)
 int launch_cg_xupdate(hipStream_t s, float *x, const float *d, long n, const double *rr, const double *dq);
+// the CG iteration with device-resident scalars in three launches: per-block partial sums of a dot product (`parts`: room for
+// dot_parts_stride() doubles), consumed by the next launch, which sums them itself (reduce_final_kernel's order)
+int launch_dot_parts(hipStream_t s, const float *a, const float *b, long n, double *parts);
+int launch_cg_step_parts(hipStream_t s, float *x, float *r, const float *d, const float *q, long n, const double *rr, const double *dq_parts,
+                         double *dq_out, double *rr_parts);
+int launch_cg_dir_parts(hipStream_t s, float *d, const float *r, long n, const double *rr_parts, const double *rr_old, double *rr_out);
+int dot_parts_stride();
 // d = r + (rr_new/rr_old) d
 int launch_cg_dir(hipStream_t s, float *d, const float *r, long n, const double *rr_new, const double *rr_old);
 // r = b - q

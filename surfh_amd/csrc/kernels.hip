@@ -916,6 +916,57 @@ __global__ __launch_bounds__(TPB) void cg_dir_kernel(float *__restrict__ d, cons
     for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) d[i] = r[i] + beta * d[i];
 }
 
+// ---- CG iteration with device-resident scalars in three launches (dot partials, step, direction) and no copies: a launch sums
+// the previous launch's per-block partial sums itself, every block for itself and in reduce_final_kernel's order (same bits),
+// instead of waiting for a one-block reduction launch in between.
+__device__ inline double parts_sum(const double *__restrict__ scratch, int nparts) {      // valid in every thread
+    __shared__ double smp[TPB / 64];
+    __shared__ double tot;
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += TPB) s += scratch[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if ((threadIdx.x & 63) == 0) smp[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int k = 0; k < TPB / 64; ++k) t += smp[k];
+        tot = t;
+    }
+    __syncthreads();
+    return tot;
+}
+
+// x += (rr / d.q) d;  r -= (rr / d.q) q;  partial sums of r.r;  d.q = the sum of `dq_parts`
+__global__ __launch_bounds__(TPB) void cg_step_parts_kernel(float *__restrict__ x, float *__restrict__ r, const float *__restrict__ d,
+                                                            const float *__restrict__ q, long n, const double *__restrict__ rr,
+                                                            const double *__restrict__ dq_parts, int nparts, double *__restrict__ dq_out,
+                                                            double *__restrict__ scratch) {
+    const double dq = parts_sum(dq_parts, nparts);
+    if (blockIdx.x == 0 && threadIdx.x == 0) dq_out[0] = dq;
+    const float step = (float)(rr[0] / dq);
+    double s = 0.0;
+    const long stride = (long)gridDim.x * TPB;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) {
+        x[i] += step * d[i];
+        const float rn = r[i] - step * q[i];
+        r[i] = rn;
+        s += (double)rn * (double)rn;
+    }
+    s = block_sum(s);
+    if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+}
+
+// rr' = the sum of `rr_parts` -> rr_out (a slot nobody reads in this launch);  d = r + (rr' / rr_old) d
+__global__ __launch_bounds__(TPB) void cg_dir_parts_kernel(float *__restrict__ d, const float *__restrict__ r, long n,
+                                                           const double *__restrict__ rr_parts, int nparts,
+                                                           const double *__restrict__ rr_old, double *__restrict__ rr_out) {
+    const double rrn = parts_sum(rr_parts, nparts);
+    if (blockIdx.x == 0 && threadIdx.x == 0) rr_out[0] = rrn;
+    const float beta = (float)(rrn / rr_old[0]);
+    const long stride = (long)gridDim.x * TPB;
+    for (long i = (long)blockIdx.x * TPB + threadIdx.x; i < n; i += stride) d[i] = r[i] + beta * d[i];
+}
+
 __global__ __launch_bounds__(TPB) void residual_kernel(float *__restrict__ r, const float *__restrict__ b,
                                                        const float *__restrict__ q, long n) {
     const long stride = (long)gridDim.x * TPB;
@@ -1409,6 +1460,23 @@ int launch_cg_step(hipStream_t s, float *x, float *r, const float *d, const floa
     hipLaunchKernelGGL(reduce_final_kernel, dim3(1), dim3(TPB), 0, s, scratch, nb, out_rr);
     return (int)hipGetLastError();
 }
+
+// scratch: 2 * DOT_BLOCKS doubles.  dot(a, b) partials only (no reduction launch); the consumers below sum them
+int launch_dot_parts(hipStream_t s, const float *a, const float *b, long n, double *parts) {
+    hipLaunchKernelGGL(dot_partial_kernel, dim3(nblocks(n, DOT_BLOCKS)), dim3(TPB), 0, s, a, b, n, parts);
+    return (int)hipGetLastError();
+}
+int launch_cg_step_parts(hipStream_t s, float *x, float *r, const float *d, const float *q, long n, const double *rr, const double *dq_parts,
+                         double *dq_out, double *rr_parts) {
+    const int nb = nblocks(n, DOT_BLOCKS);
+    hipLaunchKernelGGL(cg_step_parts_kernel, dim3(nb), dim3(TPB), 0, s, x, r, d, q, n, rr, dq_parts, nb, dq_out, rr_parts);
+    return (int)hipGetLastError();
+}
+int launch_cg_dir_parts(hipStream_t s, float *d, const float *r, long n, const double *rr_parts, const double *rr_old, double *rr_out) {
+    hipLaunchKernelGGL(cg_dir_parts_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, d, r, n, rr_parts, nblocks(n, DOT_BLOCKS), rr_old, rr_out);
+    return (int)hipGetLastError();
+}
+int dot_parts_stride() { return DOT_BLOCKS; }
 
 int launch_cg_xupdate(hipStream_t s, float *x, const float *d, long n, const double *rr, const double *dq) {
     hipLaunchKernelGGL(cg_xupdate_kernel, dim3(nblocks(n)), dim3(TPB), 0, s, x, d, n, rr, dq);

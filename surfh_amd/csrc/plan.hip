@@ -2168,50 +2168,60 @@ int surfh_cg_iter_dev(surfh_plan *p, float *x, float *r, float *d, const float *
     HIP_OK(hipStreamSynchronize(p->stream));   // also covers the pageable rr_in copy
     return 0;
 }
-// ---- the same blocks with every scalar kept on the device: nothing here synchronises with the host.  dscal[0] = r.r of the
-// current iterate, the trace goes to cg_hist (read back with surfh_cg_trace).  For the multi-GPU loop: the only other work of an
-// iteration is the normal operator and the all-reduce, both asynchronous on the plan's stream.
+// ---- the same blocks with every scalar kept on the device: nothing here synchronises with the host.  The trace cg_hist IS the
+// scalar store: r.r of the current iterate is its last entry, an iteration reads it there and writes the next entry (read back
+// with surfh_cg_trace).  An iteration is three launches -- partial sums of d.q; step (sums them, leaves partial sums of the new
+// r.r); direction (sums those) -- and no copies (round 2: five launches and two 8-byte device-to-device copies, 42 us of an
+// iteration's 2.87 ms on config 3).  For the multi-GPU loop: the only other work of an iteration is the normal operator and
+// the all-reduce, both asynchronous on the plan's stream.
 static constexpr int CG_HIST_CAP = 1 << 16;
-static int cg_hist_push(surfh_plan *p, const double *src) {
+static int cg_hist_room(surfh_plan *p) {
     if (!p->cg_hist && dev_alloc(&p->cg_hist, (size_t)CG_HIST_CAP)) return 1;
     if (p->cg_hist_n >= CG_HIST_CAP) return fail("CG trace full (%d iterations): read it with surfh_cg_trace", CG_HIST_CAP);
-    HIP_OK(hipMemcpyAsync(p->cg_hist + p->cg_hist_n, src, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-    ++p->cg_hist_n;
     return 0;
 }
 int surfh_cg_begin_dev(surfh_plan *p, const float *r, int64_t n) {         /* rr = r.r; trace restarts with it */
     if (!p) return fail("null plan");
     HIP_OK(hipSetDevice(p->dev));
     p->cg_hist_n = 0;
-    LAUNCH_OK(launch_dot(p->stream, r, r, n, p->dscratch, p->dscal + 0));
-    return cg_hist_push(p, p->dscal + 0);
+    if (cg_hist_room(p)) return 1;
+    LAUNCH_OK(launch_dot(p->stream, r, r, n, p->dscratch, p->cg_hist + 0));
+    p->cg_hist_n = 1;
+    return 0;
 }
 int surfh_cg_iter_nosync_dev(surfh_plan *p, float *x, float *r, float *d, const float *q, int64_t n) {
     if (!p) return fail("null plan");
     HIP_OK(hipSetDevice(p->dev));
-    LAUNCH_OK(launch_dot(p->stream, d, q, n, p->dscratch, p->dscal + 1));
-    LAUNCH_OK(launch_cg_step(p->stream, x, r, d, q, n, p->dscal + 0, p->dscal + 1, p->dscratch, p->dscal + 2));
-    LAUNCH_OK(launch_cg_dir(p->stream, d, r, n, p->dscal + 2, p->dscal + 0));
-    HIP_OK(hipMemcpyAsync(p->dscal + 0, p->dscal + 2, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-    return cg_hist_push(p, p->dscal + 2);
+    if (p->cg_hist_n < 1) return fail("surfh_cg_iter_nosync_dev before surfh_cg_begin_dev");
+    if (cg_hist_room(p)) return 1;
+    double *const rr = p->cg_hist + p->cg_hist_n - 1, *const pa = p->dscratch, *const pb = p->dscratch + dot_parts_stride();
+    LAUNCH_OK(launch_dot_parts(p->stream, d, q, n, pa));
+    LAUNCH_OK(launch_cg_step_parts(p->stream, x, r, d, q, n, rr, pa, p->dscal + 1, pb));
+    LAUNCH_OK(launch_cg_dir_parts(p->stream, d, r, n, pb, rr, rr + 1));
+    ++p->cg_hist_n;
+    return 0;
 }
 /* the residual-refresh iteration of qmm.lcg in two halves around the caller's normal operator on x:
  * x += (rr / d.q) d   ...   r = b - q; rr' = r.r; d = r + (rr' / rr) d; rr = rr'                                   */
 int surfh_cg_xupdate_nosync_dev(surfh_plan *p, float *x, const float *d, const float *q, int64_t n) {
     if (!p) return fail("null plan");
     HIP_OK(hipSetDevice(p->dev));
+    if (p->cg_hist_n < 1) return fail("surfh_cg_xupdate_nosync_dev before surfh_cg_begin_dev");
     LAUNCH_OK(launch_dot(p->stream, d, q, n, p->dscratch, p->dscal + 1));
-    LAUNCH_OK(launch_cg_xupdate(p->stream, x, d, n, p->dscal + 0, p->dscal + 1));
+    LAUNCH_OK(launch_cg_xupdate(p->stream, x, d, n, p->cg_hist + p->cg_hist_n - 1, p->dscal + 1));
     return 0;
 }
 int surfh_cg_refresh_nosync_dev(surfh_plan *p, float *r, const float *b, const float *q, float *d, int64_t n) {
     if (!p) return fail("null plan");
     HIP_OK(hipSetDevice(p->dev));
+    if (p->cg_hist_n < 1) return fail("surfh_cg_refresh_nosync_dev before surfh_cg_begin_dev");
+    if (cg_hist_room(p)) return 1;
+    double *const rr = p->cg_hist + p->cg_hist_n - 1, *const pb = p->dscratch + dot_parts_stride();
     LAUNCH_OK(launch_residual(p->stream, r, b, q, n));
-    LAUNCH_OK(launch_dot(p->stream, r, r, n, p->dscratch, p->dscal + 2));
-    LAUNCH_OK(launch_cg_dir(p->stream, d, r, n, p->dscal + 2, p->dscal + 0));
-    HIP_OK(hipMemcpyAsync(p->dscal + 0, p->dscal + 2, sizeof(double), hipMemcpyDeviceToDevice, p->stream));
-    return cg_hist_push(p, p->dscal + 2);
+    LAUNCH_OK(launch_dot_parts(p->stream, r, r, n, pb));
+    LAUNCH_OK(launch_cg_dir_parts(p->stream, d, r, n, pb, rr, rr + 1));
+    ++p->cg_hist_n;
+    return 0;
 }
 /* synchronises the plan's stream and copies the r.r trace (entry 0 = surfh_cg_begin_dev); returns the number of entries */
 int32_t surfh_cg_trace(surfh_plan *p, double *out, int32_t cap) {
