@@ -14,8 +14,8 @@ $C -o _bin/copy_bw copy_bw.hip &
 $C -o _bin/stride_bw stride_bw.hip &
 $C -o _bin/mall_copy mall_copy.hip &
 $C -DWPS=1 -DDEPTH=3 -o _bin/rx3v2 rx3v2.hip &
-$C -o _bin/ct ../../surfh_amd/csrc/dft_ct.hip ct_main.hip &               # the Cooley-Tukey pass: check against float64 + timing
+$C -o _bin/ct ../../surfh_amd/csrc/dft_ct.hip dft_dif.hip ct_main.hip &   # the Cooley-Tukey pass (and its DIF variant): check against float64 + timing
 for e in 2 4 6 32 64 256 512 1024; do   # ... with one cost removed at a time (CT_EXP in dft_ct.hip)
-  $C -DCT_EXP=$e -o _bin/ct_e$e ../../surfh_amd/csrc/dft_ct.hip ct_main.hip &
+  $C -DCT_EXP=$e -o _bin/ct_e$e ../../surfh_amd/csrc/dft_ct.hip dft_dif.hip ct_main.hip &
 done
 wait

@@ -91,6 +91,8 @@ static int compare(const char *what, const float *a, const float *b, long rows, 
     return rel < 2e-6 ? 0 : 1;
 }
 
+int launch_dft_dif(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl);      // dft_dif.hip: the c2c pass as a DIF step, independent waves
+
 int main(int argc, char **argv) {
     const int N = argc > 1 ? atoi(argv[1]) : 501;
     const int LPc = argc > 2 ? atoi(argv[2]) : 256;
@@ -127,6 +129,10 @@ int main(int argc, char **argv) {
             hipLaunchKernelGGL(ref_k, dim3((unsigned)(((long)N * ncx * B + 255) / 256)), dim3(256), 0, 0, r);
             CK(hipDeviceSynchronize());
             bad += compare(dir ? "c2c inverse" : "c2c forward", b, c, N, ldx, ldx, acc);
+            CK(hipMemset(b, 0, nel * 4));
+            CK(launch_dft_dif(0, g, pl));
+            CK(hipDeviceSynchronize());
+            bad += compare(dir ? "c2c inverse (DIF)" : "c2c forward (DIF)", b, c, N, ldx, ldx, acc);
         }
         {   // r2c: real [N][B][2 ncx] -> complex rows 0..Nh [B][2 ncx][2]
             const long ldr = (long)B * ncx * 2, ldo = (long)B * ncx * 4;
@@ -198,6 +204,18 @@ int main(int argc, char **argv) {
             // half-spectrum arrays hold N/2+1 rows of 2x wide rows: same bytes per row pair
             g.ldb = cs.loader == DFT_CT_HPACK ? 2 * ldx : ldx; g.sB = cs.loader == DFT_CT_HPACK ? ncx * 4 : ncx * 2;
             g.ldc = cs.epi == DFT_CT_HSEP ? 2 * ldx : ldx; g.sC = cs.epi == DFT_CT_HSEP ? ncx * 4 : ncx * 2;
+            if (&cs == &cases[0]) {       // the same pass as a DIF step
+                for (int w = 0; w < 2; ++w) CK(launch_dft_dif(0, g, pl));
+                hipEventRecord(e0, 0);
+                const int repsd = getenv("CT_REPS") ? atoi(getenv("CT_REPS")) : 5;
+                for (int w = 0; w < repsd; ++w) CK(launch_dft_dif(0, g, pl));
+                hipEventRecord(e1, 0);
+                CK(hipDeviceSynchronize());
+                float msd = 0;
+                hipEventElapsedTime(&msd, e0, e1);
+                msd /= repsd;
+                printf("time %-28s %.3f ms   %.2f GB -> %.2f TB/s\n", "c2c forward (DIF)", msd, cs.gb, cs.gb / msd);
+            }
             for (int w = 0; w < 2; ++w) CK(launch_dft_ct(0, g, pl));
             hipEventRecord(e0, 0);
             const int reps = getenv("CT_REPS") ? atoi(getenv("CT_REPS")) : 5;      // CT_REPS=300: sustained load (the clock settles)
