@@ -115,15 +115,25 @@ def result_dir_name(method, n_channels, n_templates, niter, hyper_parameter, sca
     return f'{method}_MC_{n_channels}_MO_4_Temp_{n_templates}_nit_{str(niter)}_mu_{str("{:.2e}".format(hyper_parameter))}_SD_{scale_data}/'
 
 
-def reconstruction_method(spectro_model, ndata, templates, result_path, hyper_parameter, niter, method, scale_data):
-    """main_fusion.py:162-206: regularised least squares by CG, then the three result files."""
+def reconstruction_method(spectro_model, ndata, templates, result_path, hyper_parameter, niter, method, scale_data,
+                          checkpoint_every=0, resume=None):
+    """main_fusion.py:162-206: regularised least squares by CG, then the three result files.  Not in the reference:
+    `checkpoint_every` > 0 writes the iterate to checkpoint.npz in the result directory every that many iterations,
+    `resume` (such a file) warm-starts from it and runs the iterations that are left."""
     value_init = 0
     path = pathlib.Path(result_path) / result_dir_name(method, len(spectro_model.instrs), templates.shape[0], niter,
                                                        hyper_parameter, scale_data)
     path.mkdir(parents=True, exist_ok=True)
     crit = QuadCriterion_MRS(mu_spectro=1, y_spectro=np.copy(ndata), model_spectro=spectro_model,
                              mu_reg=hyper_parameter, printing=True, gradient="separated")
-    res = crit.run_method(method, niter, perf_crit=1, calc_crit=True, value_init=value_init)
+    if resume:
+        from surfh_amd.fusion import load_checkpoint
+        x_saved, it_done, _ = load_checkpoint(resume)
+        value_init = np.asarray(x_saved, dtype=np.float64).reshape(crit.shape_of_output)
+        print(f"Resuming from {resume}: {it_done} iterations done, {max(niter - it_done, 0)} to go")
+        niter = max(niter - it_done, 0)
+    ck = (path / 'checkpoint.npz', checkpoint_every) if checkpoint_every and checkpoint_every > 0 else None
+    res = crit.run_method(method, niter, perf_crit=1, calc_crit=True, value_init=value_init, checkpoint=ck)
     y_cube = spectro_model.mapsToCube(res.x)
     print(f"Results save in {path}")
     np.save(path / 'res_x.npy', res.x)
@@ -156,7 +166,10 @@ def synthetic_problem(name, npix):
               help='Run on a synthetic benchmark problem (small, config2, config3, config4) instead of fusion_dir inputs; '
                    'results go to <fusion_dir>/Results/.')
 @click.option('--device', default=0, type=int, help='GPU index.')
-def main(fusion_dir, npix, hyper_parameter, niter, n_templates, scale_data, method, verbose, synthetic, device):
+@click.option('--checkpoint_every', default=0, type=int, help='Write the iterate to checkpoint.npz every that many iterations (0: never).')
+@click.option('--resume', default=None, type=str, help='checkpoint.npz of an interrupted run to warm-start from.')
+def main(fusion_dir, npix, hyper_parameter, niter, n_templates, scale_data, method, verbose, synthetic, device, checkpoint_every=0,
+         resume=None):
     print('options:', dict(fusion_dir=fusion_dir, npix=npix, hyper_parameter=hyper_parameter, niter=niter,
                            n_templates=n_templates, scale_data=scale_data, method=method, synthetic=synthetic, device=device))
     if verbose:
@@ -189,7 +202,8 @@ def main(fusion_dir, npix, hyper_parameter, niter, n_templates, scale_data, meth
         ndata = model.real_data_janskySR_to_jansky(ndata)
 
     log.info(f'Start {method} algorithm')
-    reconstruction_method(model, ndata, templates, paths["result_path"], hyper_parameter, niter, method, scale_data)
+    reconstruction_method(model, ndata, templates, paths["result_path"], hyper_parameter, niter, method, scale_data,
+                          checkpoint_every=checkpoint_every, resume=resume)
     model.close()
 
 

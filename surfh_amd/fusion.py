@@ -49,13 +49,18 @@ class QuadCriterion_MRS:
         self.L_crit_val = []
 
     def run_method(self, method="lcg", maximum_iterations=10, tolerance=1e-12, calc_crit=False, perf_crit=None,
-                   value_init=0.5):
+                   value_init=0.5, checkpoint=None):
         """fusion_CT.py:118-238.  The four callback modes of the reference:
         calc_crit / perf_crit = False/None: none; False/set: print the gradient norm every iteration;
         True/set: print it and, at iterations 1, 6, 11, ... (``self.it % 5 == 2`` after the increment, :172-175),
         evaluate the criterion (one extra forward) into ``L_crit_val``; True/None: the reference hands
         ``get_crit_val`` itself to qmm as the callback, which receives an OptimizeResult and cannot work -- here the
-        criterion of every iterate is recorded in ``L_crit_val`` instead."""
+        criterion of every iterate is recorded in ``L_crit_val`` instead.
+
+        ``checkpoint=(path, every)`` (not in the reference, which saves its result once at the end, main_fusion.py:202-204):
+        the iterate is written to ``path`` (.npz: x, it, grad_norm) every ``every`` iterations, through a temporary file and a
+        rename, so an interrupted run restarts from ``load_checkpoint(path)`` as ``value_init`` (a warm start of the solver,
+        fusion_CT.py:122-126: the search directions start afresh)."""
         assert isinstance(self.mu_reg, (int, float))       # fusion_CT.py:119
         solver = self.model_spectro.cg if method == "lcg" else self.model_spectro.mmmg     # fusion_CT.py:194-198
         # the regulariser is state of the plan: select this criterion's for the duration of the solve and put back what was
@@ -95,6 +100,16 @@ class QuadCriterion_MRS:
             callback = print_last_grad_norm_and_crit
         else:
             callback = None
+        if checkpoint is not None:
+            ck_path, ck_every = checkpoint
+            ck_every = int(ck_every)
+            user_cb, done = callback, [0]
+
+            def callback(it, gn, x):
+                done[0] += 1
+                if ck_every > 0 and done[0] % ck_every == 0:
+                    save_checkpoint(ck_path, x, done[0], gn)
+                return user_cb(it, gn, x) if user_cb is not None else None
         t0 = time.time()
         try:
             x, gn, nit = solver(self.y_spectro, mu=self.mu_spectro, mu_reg=self.mu_reg, x0=init,
@@ -124,6 +139,26 @@ class QuadCriterion_MRS:
 # ------------------------------------------------------------------------------------------------
 # multi-GPU
 # ------------------------------------------------------------------------------------------------
+def save_checkpoint(path, x, it, grad_norm):
+    """Iterate, iteration count and r.r trace as one .npz, written beside `path` first and renamed over it."""
+    path = str(path)
+    if not path.endswith(".npz"):
+        path += ".npz"
+    tmp = path[:-4] + ".tmp.npz"
+    np.savez(tmp, x=np.asarray(x, dtype=np.float64), it=np.int64(it), grad_norm=np.asarray(list(grad_norm), dtype=np.float64))
+    os.replace(tmp, path)
+    return path
+
+
+def load_checkpoint(path):
+    """(x, iterations done, r.r trace) of a file written by ``save_checkpoint``."""
+    path = str(path)
+    if not path.endswith(".npz"):
+        path += ".npz"
+    with np.load(path, allow_pickle=False) as f:
+        return f["x"], int(f["it"]), f["grad_norm"]
+
+
 def band_cost(n_pix: int, geo) -> float:
     """Estimated time (microseconds) of one band per CG iteration, from the rates measured on MI355X
     (profiles/r02_bench_config3.json): R/R^T at 445 TFLOP/s algorithmic, the two folded 2-D transforms at

@@ -80,3 +80,15 @@ def test_partition_choice(monkeypatch):
                     assert iv[0][0] == 0 and all(iv[i][1] == iv[i + 1][0] for i in range(len(iv) - 1))
                 else:                          # (i, n) equal parts
                     assert sorted(u[0] for u in parts) == list(range(parts[0][1]))
+
+
+def test_checkpoint_file_round_trip(tmp_path):
+    """save_checkpoint / load_checkpoint: one .npz written through a temporary file, loadable without pickle."""
+    from surfh_amd.fusion import load_checkpoint, save_checkpoint
+    x = np.random.default_rng(0).random((4, 8, 8)).astype(np.float32)
+    p = save_checkpoint(tmp_path / "ck", x, 7, [3.0, 2.0, 1.0])
+    assert p.endswith("ck.npz") and not (tmp_path / "ck.tmp.npz").exists()
+    x2, it, gn = load_checkpoint(tmp_path / "ck")
+    assert it == 7 and x2.dtype == np.float64 and np.array_equal(x2, x.astype(np.float64)) and list(gn) == [3.0, 2.0, 1.0]
+    save_checkpoint(tmp_path / "ck.npz", x * 2, 8, [1.0])                 # overwrites in place
+    assert load_checkpoint(tmp_path / "ck.npz")[1] == 8

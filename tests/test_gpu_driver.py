@@ -157,6 +157,37 @@ def test_driver_end_to_end(tmp_path):
     assert np.isfinite(x).all() and np.linalg.norm(x) > 0 and truth.shape == (4, 251, 251)
 
 
+def test_driver_checkpoint_and_resume(tmp_path):
+    """--checkpoint_every writes the iterate (atomically) while the solver runs; --resume warm-starts from it and runs the rest.
+    The resumed run restarts the search directions, so its result agrees with the uninterrupted one only approximately; what
+    is asserted: the checkpoint is the uninterrupted run's iterate at that iteration, and resuming lowers the criterion."""
+    from surfh_amd.fusion import load_checkpoint
+    spec = importlib.util.spec_from_file_location("main_fusion", os.path.join(ROOT, "scripts", "main_fusion.py"))
+    drv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(drv)
+    base = ["-np", "251", "-hp", "5e3", "--synthetic", "small"]
+    r = CliRunner().invoke(drv.main, ["-fd", str(tmp_path / "a"), "-ni", "4", "--checkpoint_every", "2"] + base)
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    da = tmp_path / "a" / "Results" / drv.result_dir_name("lcg", 1, 4, 4, 5e3, False)
+    xck, it, gn = load_checkpoint(da / "checkpoint.npz")
+    assert it == 4 and xck.size == 4 * 251 * 251 and len(gn) == 5
+    assert rel(xck.ravel(), np.load(da / "res_x.npy")) < 1e-6            # the last checkpoint is the final iterate
+    assert not (da / "checkpoint.tmp.npz").exists()
+    # an "interrupted" run of 2 iterations, then 8 in total resumed from its checkpoint
+    r = CliRunner().invoke(drv.main, ["-fd", str(tmp_path / "b"), "-ni", "2", "--checkpoint_every", "2"] + base)
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    db = tmp_path / "b" / "Results" / drv.result_dir_name("lcg", 1, 4, 2, 5e3, False)
+    x2, it2, _ = load_checkpoint(db / "checkpoint.npz")
+    assert it2 == 2
+    r = CliRunner().invoke(drv.main, ["-fd", str(tmp_path / "c"), "-ni", "8", "--resume", str(db / "checkpoint.npz")] + base)
+    assert r.exit_code == 0, r.output + repr(r.exception)
+    assert "2 iterations done, 6 to go" in r.output
+    dc = tmp_path / "c" / "Results" / drv.result_dir_name("lcg", 1, 4, 8, 5e3, False)     # named by the total, as an uninterrupted run
+    crit_c = np.load(dc / "criterion.npy")
+    crit_b = np.load(db / "criterion.npy")
+    assert crit_c[-1] < crit_b[-1]                                        # the resumed iterations keep descending
+
+
 def test_joint_prior(setup):
     """``gradient="joint"`` (Difference_Operator_Joint, fusion_CT.py:45-62,141-150): the device stencil is D^T D with
     D = ir2fr(laplacian(2)) restated (udft absent: parity unpinned) -- checked against the oracle's Fourier-domain form of the
