@@ -20,14 +20,18 @@
  *   - arithmetic type: fp32 on device.  The dense stages evaluate every fp32 product as a few 16-bit
  *     matrix-core products of split operands, accumulated in fp32: the spectral blur as three products of a
  *     two-piece round-to-nearest fp16 split (22 mantissa bits) with per-row / per-segment operand scales, the DFT passes
- *     the same way under a per-column running block exponent (image sizes beyond their limits: six products of an exact
- *     three-piece bf16 split); fp32-input MFMA kernels behind SURFH_* environment switches; inner products of the
+ *     the same way under a per-column running block exponent (axis lengths neither transform kernel covers -- a prime
+ *     above 255, fewer than 32 points: dense fp32-input MFMA products); fp32-input MFMA kernels behind SURFH_*
+ *     environment switches; inner products of the
  *     solvers accumulate in fp64.  surfh_config.verify selects float64-accumulating kernels throughout.
- *   - environment switches read at plan creation (A/B paths, all parity-tested): SURFH_DFT_H2=0, SURFH_DFT_RX3=0,
- *     SURFH_DFT_DENSE=1, SURFH_NO_FUSED_MIX=1, SURFH_DFT_PACKED=0, SURFH_WBLUR_FP32=1, SURFH_ADJ_FUSED=0 (separate
- *     adjoint reduction kernel), SURFH_ALPHA_RANGE=0 (transform the whole cube), SURFH_GATHER_SORTED=0,
- *     SURFH_GATHER_GROUPED=0, SURFH_SCATTER_GROUPED=0, SURFH_SCATTER_RMW_ALL=1, SURFH_ADJ_CLEAR=1, SURFH_OVERLAP=1;
- *     read once per process: SURFH_NORMAL_FUSED=0 (the normal operator goes through y).
+ *   - environment switches read at plan creation (A/B paths, parity-tested where they engage): SURFH_DFT_H2=0 (axes
+ *     <= 255 on the Cooley-Tukey kernel too), SURFH_DFT_CT=0, SURFH_DFT_DENSE=1, SURFH_NO_FUSED_MIX=1, SURFH_WBLUR_FP32=1,
+ *     SURFH_WBLUR_FAR=0, SURFH_WBLUR_PERM=0, SURFH_GEMM_GROUPED=0, SURFH_ADJ_FUSED=0 (separate adjoint reduction kernel),
+ *     SURFH_OTF_SUPPORT=0, SURFH_OTF_RANGES=0, SURFH_ALPHA_RANGE=0 (transform the whole cube), SURFH_GATHER_SORTED=0,
+ *     SURFH_GATHER_GROUPED=0, SURFH_SCATTER_GROUPED=0, SURFH_SCATTER_RMW_ALL=1, SURFH_ADJ_CLEAR=1, SURFH_OVERLAP=1,
+ *     SURFH_PLANES_NATIVE=0; surfh_config.exact switches the far class / the support lists off per plan; read per call:
+ *     SURFH_SPECTRAL_CG=0 (solver vectors = maps); read once per process: SURFH_NORMAL_FUSED=0 (the normal operator
+ *     goes through y).
  */
 #ifndef SURFH_AMD_H
 #define SURFH_AMD_H

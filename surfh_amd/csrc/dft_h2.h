@@ -12,7 +12,7 @@
 //   kind 1 (real -> complex, folded):   X0 = E, X1 = O of the real source;  out[r] = (e0 acc1, e3 acc2)
 //   kind 2 (complex -> real, plain rows): X0 = re, X1 = im;  out[r] = e0 acc1 + e1 acc2, out[Rn-r] = e2 acc1 + e3 acc2
 //
-// What differs from dft_rx3.h is how the operands reach the matrix cores:
+// How the operands reach the matrix cores (against the round-1 split-bf16 kernel, tools/exp/dft_rx3.h):
 //   * matrices: both 128 x 128 folded matrices of a pass, cut into (hi, lo) fp16 pieces at a common power-of-two
 //     scale 2^kA, are one 128 KB image (`dft_h2_build_image`) that every workgroup copies into LDS once.  No matrix
 //     traffic and NO BARRIER inside the k loop: the eight waves of a workgroup run decoupled, so one wave's loads,
@@ -25,8 +25,8 @@
 //     of a column is set by the first k-step of a tile and lowered (accumulators rescaled by the exact power of two)
 //     only if a later k-step would overflow; it never rises, so small late values keep an absolute error of 2^-35 of
 //     the column's largest value.
-// Needs 16 < N/2+1 <= 128 on both axes (the image must fit LDS) and row offsets below 4 GB; plans fall back to
-// dft_rx3 (planar complex arrays) otherwise.
+// Needs 16 < N/2+1 <= 128 on the axis (the image must fit LDS) and row offsets below 4 GB; longer axes run dft_ct.h (one
+// Cooley-Tukey step around the same loop), an axis neither covers puts the plan on dense fp32 products (planar arrays).
 #pragma once
 #include <hip/hip_runtime.h>
 

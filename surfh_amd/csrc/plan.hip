@@ -1568,7 +1568,6 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
     const size_t LP = (size_t)p->LP;
 
     {   // which transform kernels run decides the layout of the complex arrays: two-piece fp16 passes (default where
-        // the matrices fit LDS) keep them interleaved
         // the matrices fit LDS) keep them interleaved.  The kernel is chosen per axis: dft_h2 (16 < n/2+1 <= 128, row offsets below
         // 4 GB), else dft_ct (n = R M), else none -- then the whole plan runs the dense fp32 products on planar arrays.
         // SURFH_DFT_H2=0 / SURFH_DFT_CT=0 take a kernel out of the choice (A/B), SURFH_DFT_DENSE=1 forces the dense products.
