@@ -366,8 +366,18 @@ def test_cg_matches_oracle_lcg(c1):
     ge = float(np.max(np.abs(gn - gr) / gr))
     note("cg", err_x=e, err_gradnorm=ge, nit=n, gn_first=float(gn[0]), gn_last=float(gn[-1]))
     assert n == nit and len(gn) == nit + 1
-    # fp32 operator vs float64 oracle over 12 CG iterations of an ill-conditioned system
-    assert e < 5e-3 and ge < 0.2 and float(np.max(np.abs(gn[:5] - gr[:5]) / gr[:5])) < 1e-2
+    # fp32 vectors vs the float64 oracle over 12 CG iterations of an ill-conditioned system: the first ten iterates' r.r agree
+    # to 2e-5 (measured; asserted 2e-4), the last two amplify the rounding of the recurrences (1e-3, 2e-2, 5e-2 measured)
+    assert e < 3e-3 and ge < 0.2 and float(np.max(np.abs(gn[:10] - gr[:10]) / gr[:10])) < 2e-4
+    # the same solve on the verification plan (every long sum in float64, vectors still fp32): what is left is the vectors' rounding
+    mv = build_model(cfg, verify=True)
+    try:
+        xv, gv, _ = mv.cg(y, mu=mu, mu_reg=mur, x0=None, max_iter=nit, tol=1e-12)
+    finally:
+        mv.close()
+    ev, gev = rel(xv, ref["x"]), float(np.max(np.abs(gv[:10] - gr[:10]) / gr[:10]))
+    note("cg_verify", err_x=ev, err_gradnorm_first10=gev, err_gradnorm_last=float(abs(gv[-1] - gr[-1]) / gr[-1]))
+    assert ev < 1e-3 and gev < 5e-5 and float(np.max(np.abs(gv - gr) / gr)) < 5e-2
     c = [orc.crit_val(om, y, m.cg(y, mu=mu, mu_reg=mur, max_iter=k)[0], mu, mur) for k in (1, 4, 8)]
     assert c[0] > c[1] > c[2]
 
