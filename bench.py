@@ -180,13 +180,16 @@ def main_config5(args):
         roof = None
         if dom_cnt:
             # a step holds four 2-D transforms (x -> spectrum and product -> image, in each direction) = eight pass launches
-            bytes_launch = 0.5 * Lr * (Nf * 8 + N * N * 4)
+            # (with the OTF products formed inside the passes' loaders -- no specmix launches -- the eight launches share the stage's bytes)
+            fused_products = not any(k.startswith("specmix_") for k in prof_all)
+            bytes_launch = b_stage / (dom_cnt / max(n_all, 1)) if fused_products else 0.5 * Lr * (Nf * 8 + N * N * 4)
             ach = bytes_launch / (dom_ms / dom_cnt * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                     "traffic_source": None, "kernel": "dft_ct_kernel" if any(k.startswith("dft_ct_") for k in dft) else "dft_h2_kernel",
                     "launches": dom_cnt, "avg_ms": dom_ms / dom_cnt,
-                    "note": "per launch: half of a 2-D transform's algorithmic bytes, planes x (N (N/2+1) 8 + N^2 4) / 2; HIP-event times of the "
-                            f"{n_all} warm-up step(s)"}
+                    "note": ("per launch: an eighth of the stage's algorithmic bytes (the OTF products run inside the passes), planes x (2 N^2 4 + Nf 8) / 4"
+                             if fused_products else "per launch: half of a 2-D transform's algorithmic bytes, planes x (N (N/2+1) 8 + N^2 4) / 2") +
+                            f"; HIP-event times of the {n_all} warm-up step(s)"}
         out = {"metric": "CG-iterations/sec (forward+adjoint) on 512x512x2048 cube, 2-D deconvolution path", "value": args.steps / el, "unit": "it/s",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong", "vs_baseline": None,

@@ -29,7 +29,7 @@
  *     SURFH_WBLUR_FAR=0, SURFH_WBLUR_PERM=0, SURFH_GEMM_GROUPED=0, SURFH_ADJ_FUSED=0 (separate adjoint reduction kernel),
  *     SURFH_OTF_SUPPORT=0, SURFH_OTF_RANGES=0, SURFH_ALPHA_RANGE=0 (transform the whole cube), SURFH_GATHER_SORTED=0,
  *     SURFH_GATHER_GROUPED=0, SURFH_SCATTER_GROUPED=0, SURFH_SCATTER_RMW_ALL=1, SURFH_ADJ_CLEAR=1, SURFH_OVERLAP=1,
- *     SURFH_PLANES_NATIVE=0; surfh_config.exact switches the far class / the support lists off per plan; read per call:
+ *     SURFH_PLANES_NATIVE=0, SURFH_OTF_PROD=0 (plane-wise model: the OTF products as kernels of their own); surfh_config.exact switches the far class / the support lists off per plan; read per call:
  *     SURFH_SPECTRAL_CG=0 (solver vectors = maps); read once per process: SURFH_NORMAL_FUSED=0 (the normal operator
  *     goes through y).
  */

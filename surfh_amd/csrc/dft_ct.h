@@ -19,6 +19,12 @@
 //   loader PLAIN  rows 0 .. N-1 of interleaved complex columns (or of a REAL array read as packed pairs a + i b of
 //                 neighbouring columns: the r2c pass)
 //   loader MIX    the same with the forward model's spectral mix formed on the fly (x = src * sum_t tpl[t][l] mhat[t][k][kb])
+//   loader PROD   the same with an element-wise product formed on the fly: x = src * prod or src * conj(prod), `prod` an array of
+//                 the same shape (the 2-D deconvolution path's OTF product, spectro_blind_rectangle.py:193-237: the product
+//                 array is neither written nor read back)
+//   loader PRODADD  PROD plus a third array weighted per (row, column block): x = src * conj(prod) + add_w (dk[k] + dkb[kb]) add,
+//                 dk[k] = 2 - 2 cos(2 pi k / N), dkb likewise along the other axis (columns n = kb * LP + l): the quadratic prior of
+//                 the plane-wise normal operator, mu_r |D|^2 d^, folded into the adjoint's inverse transform (fusion_CT.py:16-43)
 //   loader HPACK  rows 0 .. N/2 of a Hermitian half spectrum, two neighbouring complex columns A, B read as Z = A + i B
 //                 with Z[N - k] = conj(A[k]) + i conj(B[k]) (the c2r pass: the transform of Z is a + i b, both real)
 //   epilogue PLAIN  N complex rows
@@ -27,7 +33,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-enum { DFT_CT_PLAIN = 0, DFT_CT_MIX = 1, DFT_CT_HPACK = 2 };
+enum { DFT_CT_PLAIN = 0, DFT_CT_MIX = 1, DFT_CT_HPACK = 2, DFT_CT_PROD = 3, DFT_CT_PRODADD = 4 };
 enum { DFT_CT_STORE = 0, DFT_CT_HSEP = 1 };
 
 struct DftCtArgs {
@@ -47,6 +53,14 @@ struct DftCtArgs {
     long PL = 0, KBP = 0;
     float mhat_self = 1.f, mhat_pair = 1.f;    // Parseval-scaled spectra of the solver (dft_h2.h)
     int mix_Nb = 0;
+    // PROD loader: second operand with the layout of src (own pitch / batch stride), +1: src * prod, -1: src * conj(prod)
+    const float *prod = nullptr;
+    long ldp = 0, sP = 0;
+    float prod_sign = 1.f;
+    // PRODADD: third operand (pitch / batch stride of src), its weight, the length of the other axis
+    const float *add = nullptr;
+    float add_w = 0.f;
+    int add_Nb = 0;
     // optional list of super-tiles (128 columns, numbered batch-major) to transform, ascending
     const int *vlist = nullptr;
     int nvalid = 0;

@@ -108,11 +108,14 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
     float *const twl = xbuf + 2 * NW * XFLOATS;                // [M][R - 1] (cos, sin)
     unsigned *const gsync = reinterpret_cast<unsigned *>(twl + (((M * (R - 1) * 2) + 3) & ~3));      // one arrival counter per group
     float4 *const mixbuf = reinterpret_cast<float4 *>(gsync + 4);
+    float *const awk = reinterpret_cast<float *>(mixbuf);      // PRODADD: weight of row k of the full transform, [N]
 
     {   // constants: global -> LDS, once
         uint4 *l4 = reinterpret_cast<uint4 *>(lds);
         for (int i = tid; i < IMGH / 8; i += NTH) l4[i] = img[i];
         for (int i = tid; i < M * (R - 1) * 2; i += NTH) twl[i] = twg[i];
+        if (LD == DFT_CT_PRODADD)
+            for (int i = tid; i < N; i += NTH) awk[i] = g.add_w * (2.f - 2.f * cospif(2.f * (float)i / (float)N));
         if (tid < 4) gsync[tid] = 0u;
     }
     // this workgroup's contiguous range of units (NG adjacent tiles of 16 columns, one per group of waves)
@@ -155,11 +158,22 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
             CT_MIXTAB(kb);                                                                                      \
             lds_barrier();                                                                                      \
         }                                                                                                       \
+    }                                                                                                           \
+    if (LD == DFT_CT_PRODADD) {                                                                                 \
+        const int kb = g.batch > 1 ? (t_) / tilesX : (((t_) % tilesX) * 16) / g.LP;                             \
+        awb = g.add_w * (2.f - 2.f * cospif(2.f * (float)kb / (float)g.add_Nb));                                \
     }
 
     // Addressing of the k loop: buffer loads with one descriptor per k-step and direction (scalar 64-bit base: no 4 GB
     // limit on rows x pitch), the row inside the step as a scalar byte offset, the lane part in one VGPR.
     const float *tp = g.src;           // first row of this wave's sub-sequence in the current tile (HPACK: row 0 of the tile)
+    const float *tpp = g.prod;         // PROD: the same row of the second operand
+    const long stepP = (long)R * g.ldp;
+    const unsigned stepP4 = (unsigned)(stepP * 4), c8 = (unsigned)(l31 >> 1) * 8u;      // both lanes of a column read its (re, im)
+    const float psig = g.prod_sign * sig;
+    constexpr bool HASPROD = (LD == DFT_CT_PROD || LD == DFT_CT_PRODADD);
+    const float *tpd = g.add;          // PRODADD: the same row of the third operand
+    float awb = 0.f;                   // ... its weight along the other axis for the tile's k_beta
 #define CT_RSRC(ptr_) __builtin_amdgcn_make_buffer_rsrc((void *)(ptr_), 0, 0xFFFFFFFF, 0x00020000)
 #define CT_BLOAD(r_, v_, s_) ((CT_EXP & 32) ? __uint_as_float((v_) + (s_)) : __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r_, (int)(v_), (int)(s_), 0)))
 #define CT_BLOAD2(r_, v_, s_) ((CT_EXP & 32) ? f32x2{__uint_as_float((v_) + (s_)), 1.f} : __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r_, (int)(v_), (int)(s_), 0)))
@@ -168,6 +182,8 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
         const int tx = (t_) % tilesX;                                                                           \
         const long bz_ = (t_) / tilesX;                                                                         \
         tp = g.src + bz_ * g.sB + (long)tx * SRC_T + (LD == DFT_CT_HPACK ? 0L : (long)n1 * g.ldb);              \
+        if (HASPROD) tpp = g.prod + bz_ * g.sP + (long)tx * SRC_T + (long)n1 * g.ldp;                           \
+        if (LD == DFT_CT_PRODADD) tpd = g.add + bz_ * g.sB + (long)tx * SRC_T + (long)n1 * g.ldb;               \
     }
     // HPACK: which k-steps hold only interior elements (every j has its mirror, every primary row R j + n1 <= N / 2 for all n1)
 #define CT_HFAST(kt_) ((kt_) >= 1 && R * (16 * (kt_) + 16) - 1 <= Nh && 16 * (kt_) + 16 <= Mh - 1)
@@ -182,6 +198,23 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
                 xr[jj] = CT_BLOAD(rp_, vk, (unsigned)jj * step4);                                               \
                 /* element 0 has no mirror (row M of the sub-sequence may not exist): both halves read row M - 8 */ \
                 qr[jj] = CT_BLOAD(rq_, (jj == 0 && (kt_) == 0) ? c4 : vq, (unsigned)(7 - jj) * step4);          \
+            }                                                                                                   \
+            if (LD == DFT_CT_PRODADD) {                                                                         \
+                const __amdgpu_buffer_rsrc_t dp_ = CT_RSRC(tpd + (long)(16 * (kt_)) * stepR);                   \
+                const __amdgpu_buffer_rsrc_t dq_ = CT_RSRC(tpd + (long)(M - 16 * (kt_) - 15) * stepR);          \
+                _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                              \
+                    xi[jj] = CT_BLOAD(dp_, vk, (unsigned)jj * step4);                                           \
+                    qi[jj] = CT_BLOAD(dq_, (jj == 0 && (kt_) == 0) ? c4 : vq, (unsigned)(7 - jj) * step4);      \
+                }                                                                                               \
+            }                                                                                                   \
+            if (HASPROD) {                                                                                      \
+                const __amdgpu_buffer_rsrc_t hp_ = CT_RSRC(tpp + (long)(16 * (kt_)) * stepP);                   \
+                const __amdgpu_buffer_rsrc_t hq_ = CT_RSRC(tpp + (long)(M - 16 * (kt_) - 15) * stepP);          \
+                const unsigned wk = (unsigned)(8 * hv) * stepP4 + c8, wq = (unsigned)(8 * (1 - hv)) * stepP4 + c8; \
+                _Pragma("unroll") for (int jj = 0; jj < 8; ++jj) {                                              \
+                    hx[jj] = CT_BLOAD2(hp_, wk, (unsigned)jj * stepP4);                                         \
+                    hm[jj] = CT_BLOAD2(hq_, (jj == 0 && (kt_) == 0) ? c8 : wq, (unsigned)(7 - jj) * stepP4);    \
+                }                                                                                               \
             }                                                                                                   \
         } else if (CT_HFAST(kt_)) {                                                                             \
             /* primary rows R j + n1 read directly, mirror elements Z[N - R j + n1] = conj of row R j - n1 */        \
@@ -215,6 +248,15 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
             const int k = (kt_) * BK + 8 * hv + jj;                                                             \
             const bool pv = PV_;                                                                                \
             float a = xr[jj], b = qr[jj];                                                                       \
+            if (HASPROD) {              /* own component of x * h (or x * conj h): x_own h_re +- x_other h_im */     \
+                a = a * hx[jj][0] + psig * (pair_swap(a) * hx[jj][1]);                                          \
+                b = b * hm[jj][0] + psig * (pair_swap(b) * hm[jj][1]);                                          \
+            }                                                                                                   \
+            if (LD == DFT_CT_PRODADD) { /* + (weight of the row + weight of the tile's k_beta) * third operand */  \
+                const int mp = R * k + n1, mq = pv ? N - R * k + n1 : mp;                                       \
+                a += (awk[mp] + awb) * xi[jj];                                                                  \
+                b += (awk[mq] + awb) * qi[jj];                                                                  \
+            }                                                                                                   \
             if (LD == DFT_CT_MIX) {     /* own component of (re + i im) * s */                                   \
                 const float ap = pair_swap(a), bp = pair_swap(b);                                               \
                 const int mp = R * k + n1, mq = pv ? N - R * k + n1 : mp;     /* rows of the full transform */   \
@@ -285,6 +327,8 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
 
     int hv = h;
     float xr[8], qr[8], xi[8], qi[8];  // raw values: elements j and mirror elements (HPACK: both floats of the lane's 8 bytes)
+    f32x2 hx[8], hm[8];                // PROD: (re, im) of the second operand at the elements / mirror elements
+    (void)hx; (void)hm;
     float x0[8], x1[8];
     f16x8 c0h, c0l, c1h, c1l;          // fragments of the current k-step
     f32x16 acc1[MAXMT], acc2[MAXMT];
@@ -563,19 +607,20 @@ __global__ __launch_bounds__(Cfg<R>::NTH) void dft_ct_kernel(DftCtArgs g, const 
 #undef CT_MAXEXP
 #undef CT_MFMA
 
-size_t ct_lds_bytes(int R, int M, int MT, int KT, bool mix) {
+size_t ct_lds_bytes(int R, int M, int MT, int KT, bool mix, bool addtab = false) {
     const int NW = (R == 2 ? 4 : 2) * R;
     size_t b = (size_t)4 * KT * (32 * MT * 16) * 2;                        // image
     b += (size_t)2 * NW * XFLOATS * 4;                                    // exchange buffers
     b += (size_t)(((M * (R - 1) * 2) + 3) & ~3) * 4 + 16;                 // twiddles, group counters
     if (mix) b += (size_t)2 * (R * M) * 2 * sizeof(float4);               // two mix tables
+    if (addtab) b += (size_t)(R * M) * sizeof(float);                     // PRODADD: row weights
     return b;
 }
 
 template <int R, int LD, int EP>
 int launch_inst(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl, int NU, int cus) {
     static unsigned long long done = 0;
-    const size_t ldsb = ct_lds_bytes(R, pl.M, pl.MT, pl.KT, LD == DFT_CT_MIX);
+    const size_t ldsb = ct_lds_bytes(R, pl.M, pl.MT, pl.KT, LD == DFT_CT_MIX, LD == DFT_CT_PRODADD);
     if (ldsb > LDS_LIMIT) return (int)hipErrorInvalidValue;
     if (int e = ensure_dynamic_lds(dft_ct_kernel<R, LD, EP>, ldsb, done)) return e;
     const dim3 grid((unsigned)(NU < cus ? NU : cus));
@@ -588,6 +633,8 @@ template <int R>
 int launch_r(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl, int NU, int cus) {
     if (g.loader == DFT_CT_PLAIN && g.epi == DFT_CT_STORE) return launch_inst<R, DFT_CT_PLAIN, DFT_CT_STORE>(stream, g, pl, NU, cus);
     if (g.loader == DFT_CT_MIX && g.epi == DFT_CT_STORE) return launch_inst<R, DFT_CT_MIX, DFT_CT_STORE>(stream, g, pl, NU, cus);
+    if (g.loader == DFT_CT_PROD && g.epi == DFT_CT_STORE) return launch_inst<R, DFT_CT_PROD, DFT_CT_STORE>(stream, g, pl, NU, cus);
+    if (g.loader == DFT_CT_PRODADD && g.epi == DFT_CT_STORE) return launch_inst<R, DFT_CT_PRODADD, DFT_CT_STORE>(stream, g, pl, NU, cus);
     if (g.loader == DFT_CT_HPACK && g.epi == DFT_CT_STORE) return launch_inst<R, DFT_CT_HPACK, DFT_CT_STORE>(stream, g, pl, NU, cus);
     if (g.loader == DFT_CT_PLAIN && g.epi == DFT_CT_HSEP) return launch_inst<R, DFT_CT_PLAIN, DFT_CT_HSEP>(stream, g, pl, NU, cus);
     return (int)hipErrorInvalidValue;
@@ -665,6 +712,10 @@ int launch_dft_ct(hipStream_t stream, const DftCtArgs &g, const DftCtPlan &pl) {
     if (!pl.img || !pl.tw || g.R != pl.R || g.M != pl.M || !g.src || !g.dst || g.ncols < 64 || g.ncols % 64 || g.batch < 1)
         return (int)hipErrorInvalidValue;
     if (g.loader == DFT_CT_MIX && (!g.mhat || !g.tpl || g.T < 1 || g.T > 4 || g.LP % 128)) return (int)hipErrorInvalidValue;
+    if ((g.loader == DFT_CT_PROD || g.loader == DFT_CT_PRODADD) &&
+        (!g.prod || g.ldp <= 0 || 16.0 * (double)g.R * (double)g.ldp * 4.0 + 1024.0 >= 4294967296.0))
+        return (int)hipErrorInvalidValue;
+    if (g.loader == DFT_CT_PRODADD && (!g.add || g.add_Nb < 1 || (g.batch == 1 && (g.LP < 16 || g.LP % 16)))) return (int)hipErrorInvalidValue;
     if ((g.loader == DFT_CT_HPACK && g.sgn < 0.f) || (g.epi == DFT_CT_HSEP && g.sgn > 0.f)) return (int)hipErrorInvalidValue;
     // 32-bit offsets inside a k-step: 16 rows of a sub-sequence; HPACK's edge steps address rows 0 .. N / 2 from the tile's first row
     if (16.0 * (double)g.R * (double)g.ldb * 4.0 + 1024.0 >= 4294967296.0) return (int)hipErrorInvalidValue;

@@ -152,6 +152,7 @@ struct surfh_plan {
     bool gather_sorted = true;                   // gather rows ordered by cube location (L2 reuse across pointings)
     bool gemm_grouped = true;                    // the adjoint's spectral-blur GEMMs of up to four channels as one launch (SURFH_GEMM_GROUPED=0: one each)
     bool scatter_grouped = true;                 // adjoint scatter with SCATTER_G neighbouring pixels per workgroup (GroupTable)
+    bool otf_prod = true;                        // plane-wise model: OTF products inside the loader of the inverse transform (SURFH_OTF_PROD=0: own kernels)
     bool gather_grouped = true;                  // forward gather (fp16 output) likewise
     bool dense_dft = false, fuse_mix = true, wblur_fp32 = false;
     // surfh_config.verify: every long sum accumulated in float64 (dense DFT products, spectral blur, adjoint spectral mix,
@@ -1076,8 +1077,21 @@ int rfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool acols = false
     return 0;
 }
 
+// element-wise product formed in the loader of the first inverse pass (dft_ct.h, loader PROD): src * prod (sign +1) or
+// src * conj(prod) (-1), times `scale` -- the plane-wise path's OTF product without its own kernel and array
+struct ProdOperand {
+    const float *prod = nullptr;
+    float sign = 1.f, scale = 1.f;
+    // + add_w |D|^2 add (loader PRODADD): the quadratic prior's term of the plane-wise normal operator, `add` = the spectrum of
+    // the vector the operator is applied to, |D|^2 = the circular first differences' transfer function (fusion_CT.py:16-43)
+    const float *add = nullptr;
+    float add_w = 0.f;
+};
+// the complex pass along alpha runs on the kernel that has the PROD loader (SURFH_OTF_PROD=0: the separate product kernels)
+bool prod_capable(const surfh_plan *p) { return p->otf_prod && p->T == 0 && p->ilv && !p->dense_dft && p->ax_a == 2; }
+
 // spec [KAP][KBP][LP][2] -> cube [NBP][NAP][LP]        (tmp ycol viewed as Y[NAP][KBP][LP][2])
-int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false, int which = 3) {
+int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool acols = false, int which = 3, const ProdOperand *po = nullptr) {
     const long LP = p->LP;
     const int hb = p->Nb / 2 + 1;
     DftCtArgs g;   // c2c along alpha (optionally with the spectral mix formed in the loader)
@@ -1088,12 +1102,18 @@ int irfft2_lam_ct(surfh_plan *p, const float *src, float *dst, bool mix, bool ac
     g.ncols = (int)(hb * LP); g.batch = 1;
     if (mix) { g.mhat = p->mhat; g.tpl = p->tpl; g.T = p->T; g.LP = (int)p->LP; g.PL = p->PL; g.KBP = p->KBP; }
     if (mix && p->spec_in) { g.mhat = p->spec_in; g.mhat_self = 1.f; g.mhat_pair = 0.70710678118654752f; g.mix_Nb = p->Nb; }
+    if (po && po->prod && !mix) {
+        g.loader = DFT_CT_PROD; g.prod = po->prod; g.ldp = g.ldb; g.sP = 0; g.prod_sign = po->sign; g.scale *= po->scale;
+        if (po->add && po->add_w != 0.f) {
+            g.loader = DFT_CT_PRODADD; g.add = po->add; g.add_w = po->add_w; g.add_Nb = p->Nb; g.LP = (int)p->LP;
+        }
+    }
     // the OTF's support: tiles outside it are neither computed nor stored -- their place in ycol_mix is zero for good
     const bool supp = mix && p->otf_vlist && p->ycol_mix && p->otf_tabs;
     float *const yc = supp ? p->ycol_mix : p->ycol;
     if (supp) { g.vlist = p->otf_vlist; g.nvalid = p->otf_nvalid; g.dst = yc; g.ktab = p->otf_tabs; g.tabLP = (int)LP; }
     if (which & 2) {
-        Prof pr(p, mix ? "dft_ct_cols_inv_mix" : "dft_ct_cols_inv");
+        Prof pr(p, mix ? "dft_ct_cols_inv_mix" : (g.loader == DFT_CT_PROD ? "dft_ct_cols_inv_prod" : g.loader == DFT_CT_PRODADD ? "dft_ct_cols_inv_prodadd" : "dft_ct_cols_inv"));
         LAUNCH_OK(launch_dft_ct(p->stream, g, p->ctA));
     }
     if (!(which & 1)) return 0;
@@ -1119,9 +1139,10 @@ int rfft2_lam_ilv(surfh_plan *p, const float *src, float *dst, float *madj = nul
     if (p->ax_b == 1 ? rfft2_lam_h2(p, src, dst, nullptr, acols, 1) : rfft2_lam_ct(p, src, dst, acols, lists, 1)) return 1;
     return p->ax_a == 1 ? rfft2_lam_h2(p, src, dst, nullptr, acols, 2) : rfft2_lam_ct(p, src, dst, acols, lists, 2);
 }
-int irfft2_lam_ilv(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
+int irfft2_lam_ilv(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false, const ProdOperand *po = nullptr) {
+    if (po && p->ax_a != 2) return fail("irfft2: the product loader needs the Cooley-Tukey pass along alpha");
     if (p->h2) return irfft2_lam_h2(p, src, dst, mix, acols);
-    if (p->ax_a == 1 ? irfft2_lam_h2(p, src, dst, mix, acols, 2) : irfft2_lam_ct(p, src, dst, mix, acols, 2)) return 1;
+    if (p->ax_a == 1 ? irfft2_lam_h2(p, src, dst, mix, acols, 2) : irfft2_lam_ct(p, src, dst, mix, acols, 2, po)) return 1;
     return p->ax_b == 1 ? irfft2_lam_h2(p, src, dst, mix, acols, 1) : irfft2_lam_ct(p, src, dst, mix, acols, 1);
 }
 
@@ -1129,8 +1150,9 @@ int irfft2_lam_ilv(surfh_plan *p, const float *src, float *dst, bool mix = false
 // pipelines on device buffers
 // ---------------------------------------------------------------------------------------------
 int rfft2_cube(surfh_plan *p, const float *src, float *dst) { return p->dense_dft ? rfft2_lam(p, src, dst) : rfft2_lam_ilv(p, src, dst); }
-int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false) {
-    return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_ilv(p, src, dst, mix, acols);
+int irfft2_cube(surfh_plan *p, const float *src, float *dst, bool mix = false, bool acols = false, const ProdOperand *po = nullptr) {
+    if (po && p->dense_dft) return fail("irfft2: the product loader is not part of the dense plan");
+    return p->dense_dft ? irfft2_lam(p, src, dst) : irfft2_lam_ilv(p, src, dst, mix, acols, po);
 }
 
 // mhat[t] = sum_l tpl[t][l] conj(sotf[l]) rfft2(cube[l])  (T > 0), or the per-plane product (T == 0)
@@ -1139,6 +1161,7 @@ int adjoint_tail(surfh_plan *p, const float *cube, bool acols = false) {
     if (p->adjmix_part && p->h2 && p->T > 0) return rfft2_lam_h2(p, cube, p->spec, p->spec_out ? p->spec_out : p->mhat, acols);
     if (p->ct && !p->dense_dft) {
         if (rfft2_lam_ilv(p, cube, p->spec, nullptr, acols, true)) return 1;
+        if (prod_capable(p)) return 0;      // plane-wise: conj(OTF) x spec is formed by the loader of the inverse transform that follows
         SpecmixAdjOpt o;
         o.Na = p->Na; o.KBP = p->KBP;
         if (p->T > 0 && p->otf_vlist && p->ycol_mix && p->otf_tabs) o.lim = p->otf_tabs + 2 * (p->LP / 128);
@@ -1198,6 +1221,11 @@ int forward_dev(surfh_plan *p, const float *x, float *y, bool hand_over = false)
         // spectral mix x OTF fused into the loader of the first inverse pass: `spec` is never written
         // (the normal operator needs the blurred cube only where a gather reads it)
         if (irfft2_cube(p, p->sotf, p->cube, true, hand_over)) return 1;
+    } else if (prod_capable(p)) {
+        // plane-wise model on the Cooley-Tukey passes: OTF x spectrum in the loader of the first inverse pass, `spec` is never written
+        ProdOperand po;
+        po.prod = p->sotf;
+        if (irfft2_cube(p, p->mhat, p->cube, false, false, &po)) return 1;
     } else {
         {
             Prof pr(p, "specmix_fwd");
@@ -1369,6 +1397,23 @@ int adjoint_dev(surfh_plan *p, const float *y, float *x, bool ref, bool handed_o
         if (irfft2_planes(p, p->mhat, p->maps_pad, p->T)) return 1;
         Prof pr(p, "unpad_planes");
         LAUNCH_OK(launch_unpad_planes(s, p->maps_pad, x, p->T, p->Na, p->Nb, p->NAP, p->NBP));
+    } else if (prod_capable(p)) {
+        // conj(OTF) x spectrum of the accumulated cube in the loader; inside the plane-wise normal operator mu rides on the pass and
+        // the quadratic prior comes in as a third operand: `mhat` still holds the spectrum of the vector the forward half was applied to
+        ProdOperand po;
+        po.prod = p->sotf; po.sign = -1.f; po.scale = p->pn_fold_prior ? (float)p->pl_mu : 1.f;
+        if (p->pn_fold_prior && p->pl_mu_reg != 0.0 && p->pl_mu != 0.0) {      // q = mu (A^T A d + (mu_r / mu) D^T D d)
+            po.add = p->mhat; po.add_w = (float)(p->pl_mu_reg / p->pl_mu);
+        }
+        float *const out = p->pn_native ? x : p->cube;
+        if (irfft2_cube(p, p->spec, out, false, false, &po)) return 1;
+        if (!p->pn_native) {
+            const long pl = (long)p->Na * p->Nb;
+            if (p->Lown < p->Lc) LAUNCH_OK(launch_fill_zero(s, x, (long)p->Lc * pl));   // planes no channel observes
+            Prof pr(p, "cube_transpose");
+            for (auto &g : p->segs)
+                LAUNCH_OK(launch_cube_from_lam_inner(s, p->cube + g.coff, x, g.start, g.len, p->Na, p->Nb, p->NAP, p->LP));
+        }
     } else if (p->pn_native) {
         if (irfft2_cube(p, p->mhat, x)) return 1;           // straight into the caller's wavelength-innermost vector
     } else {
@@ -1645,6 +1690,7 @@ int surfh_plan_create(const surfh_config *cfg, surfh_plan **out) {
         const char *e7 = getenv("SURFH_OVERLAP");
         p->overlap = e7 && e7[0] == '1';
         if (p->overlap && hipStreamCreateWithFlags(&p->stream2, hipStreamNonBlocking) != hipSuccess) return bail(fail("hipStreamCreate failed"));
+        if (const char *ep = getenv("SURFH_OTF_PROD")) p->otf_prod = !(ep[0] == '0');
         const char *e15 = getenv("SURFH_GATHER_GROUPED");
         p->gather_grouped = !(e15 && e15[0] == '0');
         { const char *eg = getenv("SURFH_GEMM_GROUPED"); p->gemm_grouped = !(eg && eg[0] == '0'); }
@@ -2553,7 +2599,9 @@ int pn_normal(surfh_plan *p, const float *v, float *q, double *dq) {
     PnScope sc(p);
     // with interleaved spectra and a prior weight the OTF product of the adjoint applies mu and adds the prior (adjoint_tail): the
     // two halves are called directly so that no scaling pass follows
-    const bool fold = p->ilv && !p->dense_dft && p->pl_mu_reg != 0.0;
+    // (plans whose inverse transform forms the OTF product in its loader -- prod_capable -- take mu and the prior on that pass)
+    const bool prod = prod_capable(p) && p->pl_mu != 0.0;
+    const bool fold = prod || (p->ilv && !p->dense_dft && p->pl_mu_reg != 0.0);
     if (fold) {
         p->pn_fold_prior = true;
         const bool ho = normal_hand_over(p);

@@ -33,10 +33,9 @@ def test_nn_gridding(mode):
     m.close()
 
 
-def blurred_case(L=None):
+def blurred_case(L=None, N=96):
     from surfh_amd import instru
     from surfh_amd.spectro_blind_rectangle import MRSBlurred
-    N = 96
     ax = orc.synthetic_axes(N, problems.STEP_DEG)
     spec = orc.ChannelSpec(1.0 / 3600, 1.2 / 3600, (0.0, 0.0), 0.0, 0.196, 12, 3000.0, np.linspace(7, 8, 10), "R")
     wav = np.array([7.6]) if L is None else np.linspace(7.0, 8.2, L)
@@ -320,6 +319,41 @@ def test_plane_wise_cg_device_resident_loop(native, monkeypatch):
         assert not x[4].any() and rr[4] == 0.0
     finally:
         m.close()
+
+
+def test_plane_wise_model_on_the_cooley_tukey_passes(monkeypatch):
+    """The 2-D deconvolution path at an image size of the Cooley-Tukey passes (300 = 2 x 150; the benchmark's 512 x 512 is
+    tests/test_gpu_fullsize.py): forward and adjoint against the oracle; by default the OTF products are formed in the loader
+    of the inverse transforms (dft_ct.h PROD / PRODADD -- inside the normal operator with mu and the quadratic prior riding on
+    the adjoint's pass), SURFH_OTF_PROD=0 keeps the separate product kernels: same results to fp32 rounding, different bits, and
+    the same iterates of the device-resident solver."""
+    import torch
+    L, mu, mur, nit = 5, 1.3, 0.07, 6
+    res = {}
+    for prod in ("1", "0"):
+        monkeypatch.setenv("SURFH_OTF_PROD", prod)
+        N, bo, m = blurred_case(L=L, N=300)
+        try:
+            rng = np.random.default_rng(21)
+            x = rng.random((L, N, N))
+            u = rng.standard_normal((L,) + tuple(bo.slices_shape)).reshape(L, -1)
+            yf, ya = m.forward(x), m.adjoint(u)
+            ef, ea = rel(yf, bo.forward(x)), rel(ya, bo.adjoint(u))
+            assert ef < TOL and ea < TOL, (prod, ef, ea)
+            y = bo.forward(x) + 1e-2 * rng.standard_normal(yf.shape)
+            xh, gn, n = m.cg(y, mu=mu, mu_reg=mur, x0=None, max_iter=nit, refresh=4)
+            dev = torch.device("cuda:0")
+            yt = torch.as_tensor(np.ascontiguousarray(y, dtype=np.float32).reshape(-1), device=dev)
+            xt = torch.zeros((L, N, N), dtype=torch.float32, device=dev)
+            m.cg_begin_dev(yt, xt, mu, mur)
+            m.cg_step_dev(nit, 4)
+            res[prod] = (yf, ya, xh, gn, xt.cpu().numpy(), m.cg_rr())
+        finally:
+            m.close()
+    a, b = res["1"], res["0"]
+    assert rel(a[0], b[0]) < 2e-6 and rel(a[1], b[1]) < 2e-6 and not np.array_equal(a[0], b[0])      # the switch engaged
+    assert rel(a[2], b[2]) < 1e-4 and rel(a[4], b[4]) < 1e-4                                        # six CG iterations either way
+    assert rel(a[4], a[2]) < 1e-4 and float(np.max(np.abs(a[5] - a[3][-1]) / a[3][-1])) < 1e-2       # device loop = host-buffer solver
 
 
 def test_slice_cube_projections():

@@ -19,11 +19,13 @@ __global__ void fill_k(float *p, long n, unsigned seed, int mode) {
     }
 }
 // reference, float64: one thread per (output row, column).  kind 0: c2c (sgn), 1: r2c forward (real rows -> rows 0..N/2),
-// 2: c2r inverse (rows 0..N/2 Hermitian -> real rows), 3: c2c inverse with the spectral mix applied to the source
+// 2: c2r inverse (rows 0..N/2 Hermitian -> real rows), 3: c2c inverse with the spectral mix applied to the source,
+// 4 / 5: c2c of src * prod / src * conj(prod) (prod = mhat, same layout as src)
 struct RefArgs {
     int kind, N; float sgn; double scale;
     const float *src; long ldb, sB; float *dst; long ldc, sC; int ncols, batch;    // ncols: complex (kind 0, 3) or real (1: source, 2: output) columns
     const float *mhat, *tpl; int T, LP; long PL, KBP;
+    double add_w = 0;      // kind 6: src * conj(prod = mhat) + add_w (dk[n] + dkb[kb]) * add (= tpl), kb = col / LP, other axis length T
 };
 __global__ void ref_k(RefArgs a) {
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -57,6 +59,18 @@ __global__ void ref_k(RefArgs a) {
                 }
                 const double r2 = xr * mr - xi * mi, i2 = xr * mi + xi * mr;
                 xr = r2; xi = i2;
+            }
+            if (a.kind >= 4) {
+                const double hr = a.mhat[(long)n * a.ldb + bz * a.sB + 2 * col];
+                const double hi = (a.kind >= 5 ? -1.0 : 1.0) * a.mhat[(long)n * a.ldb + bz * a.sB + 2 * col + 1];
+                const double r2 = xr * hr - xi * hi, i2 = xr * hi + xi * hr;
+                xr = r2; xi = i2;
+                if (a.kind == 6) {
+                    const int kb = col / a.LP;
+                    const double w = a.add_w * ((2.0 - 2.0 * cos(2.0 * M_PI * n / a.N)) + (2.0 - 2.0 * cos(2.0 * M_PI * kb / a.T)));
+                    xr += w * a.tpl[(long)n * a.ldb + bz * a.sB + 2 * col];
+                    xi += w * a.tpl[(long)n * a.ldb + bz * a.sB + 2 * col + 1];
+                }
             }
         }
         const double th = a.sgn * 2.0 * M_PI * (double)(((long)n * k) % a.N) / (double)a.N;
@@ -134,6 +148,41 @@ int main(int argc, char **argv) {
             CK(hipDeviceSynchronize());
             bad += compare(dir ? "c2c inverse (DIF)" : "c2c forward (DIF)", b, c, N, ldx, ldx, acc);
         }
+        for (int cj = 0; cj < 2; ++cj) {     // c2c inverse of src * prod and src * conj(prod): prod = array c shifted (same layout)
+            float *pr;
+            CK(hipMalloc(&pr, nel * 4));
+            hipLaunchKernelGGL(fill_k, dim3(1024), dim3(256), 0, 0, pr, (long)nel, 4242u + mode, mode);
+            DftCtArgs g;
+            g.R = R; g.M = M; g.loader = DFT_CT_PROD; g.epi = DFT_CT_STORE; g.sgn = 1.f; g.scale = (float)sc;
+            g.src = a; g.ldb = ldx; g.sB = ncx * 2; g.dst = b; g.ldc = ldx; g.sC = ncx * 2; g.ncols = (int)ncx; g.batch = B;
+            g.prod = pr; g.ldp = ldx; g.sP = ncx * 2; g.prod_sign = cj ? -1.f : 1.f;
+            CK(hipMemset(b, 0, nel * 4)); CK(hipMemset(c, 0, nel * 4));
+            CK(launch_dft_ct(0, g, pl));
+            RefArgs r{4 + cj, N, 1.f, sc, a, ldx, ncx * 2, c, ldx, ncx * 2, (int)ncx, B, pr, nullptr, 0, 0, 0, 0};
+            hipLaunchKernelGGL(ref_k, dim3((unsigned)(((long)N * ncx * B + 255) / 256)), dim3(256), 0, 0, r);
+            CK(hipDeviceSynchronize());
+            bad += compare(cj ? "c2c inverse of src * conj(prod)" : "c2c inverse of src * prod", b, c, N, ldx, ldx, acc);
+            hipFree(pr);
+        }
+        {   // c2c inverse of src * conj(prod) + weights * add: columns n = kb * LP + l, one batch entry (3 k_beta of ncx wavelengths)
+            const int hb = 3;
+            const long LP = ncx, ld = (long)hb * LP * 2;
+            float *pr, *ad;
+            CK(hipMalloc(&pr, nel * 4)); CK(hipMalloc(&ad, nel * 4));
+            hipLaunchKernelGGL(fill_k, dim3(1024), dim3(256), 0, 0, pr, (long)nel, 4243u + mode, mode);
+            hipLaunchKernelGGL(fill_k, dim3(1024), dim3(256), 0, 0, ad, (long)nel, 4244u + mode, mode);
+            DftCtArgs g;
+            g.R = R; g.M = M; g.loader = DFT_CT_PRODADD; g.epi = DFT_CT_STORE; g.sgn = 1.f; g.scale = (float)sc;
+            g.src = a; g.ldb = ld; g.sB = 0; g.dst = b; g.ldc = ld; g.sC = 0; g.ncols = (int)(hb * LP); g.batch = 1;
+            g.prod = pr; g.ldp = ld; g.sP = 0; g.prod_sign = -1.f; g.add = ad; g.add_w = 0.37f; g.add_Nb = 2 * (hb - 1) + 1; g.LP = (int)LP;
+            CK(hipMemset(b, 0, nel * 4)); CK(hipMemset(c, 0, nel * 4));
+            CK(launch_dft_ct(0, g, pl));
+            RefArgs r{6, N, 1.f, sc, a, ld, 0, c, ld, 0, (int)(hb * LP), 1, pr, ad, g.add_Nb, (int)LP, 0, 0, 0.37};
+            hipLaunchKernelGGL(ref_k, dim3((unsigned)(((long)N * hb * LP + 255) / 256)), dim3(256), 0, 0, r);
+            CK(hipDeviceSynchronize());
+            bad += compare("c2c inv. of src * conj(prod) + w add", b, c, N, ld, ld, acc);
+            hipFree(pr); hipFree(ad);
+        }
         {   // r2c: real [N][B][2 ncx] -> complex rows 0..Nh [B][2 ncx][2]
             const long ldr = (long)B * ncx * 2, ldo = (long)B * ncx * 4;
             DftCtArgs g;
@@ -196,7 +245,12 @@ int main(int argc, char **argv) {
             {"c2c forward (PLAIN/STORE)", DFT_CT_PLAIN, DFT_CT_STORE, -1.f, 2 * gbc},
             {"r2c (PLAIN/HSEP)", DFT_CT_PLAIN, DFT_CT_HSEP, -1.f, 1.5 * gbc},
             {"c2r (HPACK/STORE)", DFT_CT_HPACK, DFT_CT_STORE, 1.f, 1.5 * gbc},
+            {"c2c of src * prod (PROD/STORE)", DFT_CT_PROD, DFT_CT_STORE, 1.f, 3 * gbc},
+            {"... + w add (PRODADD/STORE)", DFT_CT_PRODADD, DFT_CT_STORE, 1.f, 4 * gbc},
         };
+        float *pr;
+        CK(hipMalloc(&pr, nel * 4));
+        hipLaunchKernelGGL(fill_k, dim3(4096), dim3(256), 0, 0, pr, (long)nel, 77u, 0);
         for (auto &cs : cases) {
             DftCtArgs g;
             g.R = R; g.M = M; g.loader = cs.loader; g.epi = cs.epi; g.sgn = cs.sgn; g.scale = (float)sc;
@@ -204,6 +258,7 @@ int main(int argc, char **argv) {
             // half-spectrum arrays hold N/2+1 rows of 2x wide rows: same bytes per row pair
             g.ldb = cs.loader == DFT_CT_HPACK ? 2 * ldx : ldx; g.sB = cs.loader == DFT_CT_HPACK ? ncx * 4 : ncx * 2;
             g.ldc = cs.epi == DFT_CT_HSEP ? 2 * ldx : ldx; g.sC = cs.epi == DFT_CT_HSEP ? ncx * 4 : ncx * 2;
+            g.prod = pr; g.ldp = ldx; g.sP = ncx * 2; g.add = pr; g.add_w = 0.1f; g.add_Nb = 2 * (Bt - 1); g.LP = (int)ncx;
             if (&cs == &cases[0]) {       // the same pass as a DIF step
                 for (int w = 0; w < 2; ++w) CK(launch_dft_dif(0, g, pl));
                 hipEventRecord(e0, 0);
@@ -227,7 +282,7 @@ int main(int argc, char **argv) {
             ms /= reps;
             printf("time %-28s %.3f ms   %.2f GB -> %.2f TB/s\n", cs.name, ms, cs.gb, cs.gb / ms);
         }
-        hipFree(a); hipFree(b);
+        hipFree(a); hipFree(b); hipFree(pr);
     }
     dft_ct_plan_destroy(&pl);
     return 0;
